@@ -1,0 +1,40 @@
+"""Per-step attention metadata shared between the runner and the layers.
+
+Same side channel as nanovllm/utils/context.py:6-50: the runner publishes the
+step's metadata before the forward pass, layers read it, the runner clears it.
+"""
+
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class Context:
+    is_prefill: bool = False
+    cu_seqlens_q: torch.Tensor | None = None
+    cu_seqlens_k: torch.Tensor | None = None
+    max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    slot_mapping: torch.Tensor | None = None
+    context_lens: torch.Tensor | None = None
+    block_tables: torch.Tensor | None = None
+
+
+_CONTEXT = Context()
+
+
+def get_context() -> Context:
+    return _CONTEXT
+
+
+def set_context(is_prefill, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0, max_seqlen_k=0,
+                slot_mapping=None, context_lens=None, block_tables=None) -> None:
+    global _CONTEXT
+    _CONTEXT = Context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                       slot_mapping, context_lens, block_tables)
+
+
+def reset_context() -> None:
+    global _CONTEXT
+    _CONTEXT = Context()

@@ -1,0 +1,138 @@
+"""The CPU oracle against vectors produced by the imported reference (tests/golden/make_goldens.py)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as L
+from oracle import model as OM
+
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def t(a, dt):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+def same(a, b):
+    assert torch.equal(a.float(), torch.from_numpy(np.asarray(b)).float())
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("h", [896, 128, 64])
+def test_rmsnorm_bit_exact(golden, name, h):
+    g, dt = golden.npz("layers"), DT[name]
+    k = f"rms_{name}_{h}_"
+    x, r, w = t(g[k + "x"], dt), t(g[k + "r"], dt), t(g[k + "w"], dt)
+    same(L.rms_norm(x, w, 1e-6), g[k + "y"])
+    y2, r2 = L.add_rms_norm(x, r, w, 1e-6)
+    same(y2, g[k + "y2"])
+    same(r2, g[k + "r2"])
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("d", [64, 128])
+def test_rope_bit_exact(golden, name, d):
+    g, dt = golden.npz("layers"), DT[name]
+    k = f"rope_{name}_{d}_"
+    table = L.build_cos_sin_cache(d, 512, 1000000.0)
+    same(table, g[f"rope_table_{d}"])
+    q2, k2 = L.rope_qk(torch.from_numpy(g[k + "pos"]), t(g[k + "q"], dt), t(g[k + "k"], dt), table)
+    same(q2, g[k + "q2"])
+    same(k2, g[k + "k2"])
+
+
+@pytest.mark.parametrize("name", list(DT))
+def test_silu_and_mul_bit_exact(golden, name):
+    g, dt = golden.npz("layers"), DT[name]
+    same(L.silu_and_mul(t(g[f"silu_{name}_x"], dt)), g[f"silu_{name}_y"])
+
+
+def test_sampler_matches_reference_draws(golden):
+    g = golden.npz("sampler")
+    logits = t(g["logits"], torch.bfloat16)
+    toks = L.sample(logits, torch.from_numpy(g["temps"]), noise=torch.from_numpy(g["noise"]))
+    assert toks.tolist() == g["tokens"].tolist()
+    # at temperature 1e-5 the fp32 softmax saturates: the reference sampler IS the argmax
+    assert g["tokens"][:2].tolist() == logits[:2].float().argmax(-1).tolist()
+    greedy = L.sample(logits, torch.zeros(6))
+    assert greedy.tolist() == logits.float().argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("tp", [1, 2, 4])
+def test_weight_sharding(golden, tp):
+    from types import SimpleNamespace
+    g = golden.npz("sharding")
+    cfg = SimpleNamespace(head_dim=8, num_attention_heads=8, num_key_value_heads=4)
+    wqkv = torch.cat([torch.from_numpy(g[k]) for k in ("wq", "wk", "wv")], 0)
+    merged = torch.cat([torch.from_numpy(g["wgate"]), torch.from_numpy(g["wup"])], 0)
+    for r in range(tp):
+        key = f"tp{tp}_r{r}_"
+        same(OM.shard_qkv(wqkv, cfg, r, tp), g[key + "qkv"])
+        same(OM.shard_merged(merged, r, tp), g[key + "merged"])
+        same(OM.shard_cols(torch.from_numpy(g["wo"]), r, tp), g[key + "row"])
+        same(OM.shard_rows(torch.from_numpy(g["emb"]), r, tp), g[key + "emb"])
+
+
+def _tiny_cfg(style, dtype):
+    from types import SimpleNamespace
+    return SimpleNamespace(vocab_size=256, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                           num_attention_heads=4, num_key_value_heads=2, head_dim=32 if style == "qwen3" else 16,
+                           max_position_embeddings=128, rms_norm_eps=1e-6, hidden_act="silu",
+                           attention_bias=(style == "qwen2"), rope_theta=1000000.0, rope_scaling=None,
+                           tie_word_embeddings=(style == "qwen2"), dtype=dtype)
+
+
+def load_tiny(golden, style, dname):
+    g, dt = golden.npz("model"), DT[dname]
+    key = f"{style}_{dname}_"
+    weights = {k[len(key) + 2:]: t(g[k], dt) for k in g.files if k.startswith(key + "w:")}
+    return g, key, _tiny_cfg(style, dt), weights
+
+
+@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
+@pytest.mark.parametrize("dname", ["fp32", "bf16"])
+def test_whole_model_bit_exact(golden, style, dname):
+    """Prefill, 3 paged decode steps and a prefix-cache prefill: logits equal the reference's bit for bit."""
+    g, key, cfg, weights = load_tiny(golden, style, dname)
+    m = OM.OracleQwen(cfg, weights, block_size=16, num_blocks=12)
+    p0, p1 = g[key + "prompt0"].tolist(), g[key + "prompt1"].tolist()
+    ctx, pos = OM.prefill_ctx([5, 19], [[3], [7, 1]], 16)
+    logits = m.compute_logits(m.forward(torch.tensor(p0 + p1), pos, ctx), ctx)
+    same(logits, g[key + "logits_prefill"])
+    lens, tables = [5, 19], [[3], [7, 1]]
+    for step in range(3):
+        lens = [n + 1 for n in lens]
+        for tb, n in zip(tables, lens):
+            if len(tb) * 16 < n:
+                tb.append(9)
+        ctx, pos = OM.decode_ctx(lens, tables, 16)
+        ids = torch.from_numpy(g[key + f"decode{step}_in"])
+        logits = m.compute_logits(m.forward(ids, pos, ctx), ctx)
+        same(logits, g[key + f"logits_decode{step}"])
+    p2 = g[key + "prompt2"].tolist()
+    ctx, pos = OM.prefill_ctx([22], [[7, 5]], 16, cached=[16])
+    logits = m.compute_logits(m.forward(torch.tensor(p2[16:]), pos, ctx), ctx)
+    same(logits, g[key + "logits_prefix_prefill"])
+
+
+def test_tp_simulation_close_to_single_rank(golden):
+    g, key, cfg, weights = load_tiny(golden, "qwen2", "fp32")
+    ctx, pos = OM.prefill_ctx([5, 19], [[3], [7, 1]], 16)
+    ids = torch.tensor(g[key + "prompt0"].tolist() + g[key + "prompt1"].tolist())
+    outs = []
+    for tp in (1, 2):
+        m = OM.OracleQwen(cfg, weights, 16, 12, tp_size=tp)
+        outs.append(m.compute_logits(m.forward(ids, pos, ctx), ctx))
+    assert torch.allclose(outs[0], outs[1], atol=1e-5)
+
+
+def test_block_hash(golden):
+    import xxhash
+    for case in golden.json("block_hash"):
+        h = xxhash.xxh64()
+        if case["prefix"] != -1:
+            h.update(case["prefix"].to_bytes(8, "little"))
+        h.update(np.array(case["tokens"], dtype=np.int64).tobytes())
+        assert h.intdigest() == case["hash"]
+    assert golden.json("block_hash")[-1]["hash"] == 8040990501003754519
