@@ -1,0 +1,86 @@
+"""ctypes binding of libnv_hip.so (the C ABI declared in include/nv_hip.h).
+
+There is no fallback: if the library is missing, or a call returns an error
+code, a RuntimeError is raised.  Tensors are passed as raw device pointers;
+PyTorch only owns the memory and the stream.
+"""
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnv_hip.so")
+
+NV_BF16, NV_F16 = 0, 1
+W_DENSE, W_INT8, W_INT4 = 0, 1, 2
+
+_p, _i, _i64, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+
+_PROTOS = {
+    "nv_version": (C.c_int, []),
+    "nv_last_error": (C.c_char_p, []),
+    "nv_rmsnorm": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _f, _i, _p]),
+    "nv_add_rmsnorm": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
+    "nv_rope_kv_store": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _f, _i64, _i, _i, _i, _i, _p]),
+    "nv_kv_store": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _p]),
+    "nv_paged_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "nv_paged_attn_decode_pick_splits": (_i, [_i, _i, _i]),
+    "nv_paged_attn_decode": (_i, [_p, _i64, _p, _p, _p, _i, _p, _p, _i64, _p, _sz, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "nv_attn_prefill": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "nv_silu_mul": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "nv_gemm_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),
+    "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
+    "nv_sample": (_i, [_p, _i64, _p, _p, _p, _i, _i, _u64, _i, _p]),
+    "nv_stage_decode_inputs": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return list(_PROTOS)
+
+
+def lib():
+    """Load the shared library once; fail loudly if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {lib().nv_last_error().decode()}")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return NV_BF16
+    if dt == torch.float16:
+        return NV_F16
+    raise TypeError(f"the HIP path computes in bf16 or fp16, got {dt}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; byox_vllm_amd has no CPU compute path")

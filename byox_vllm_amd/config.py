@@ -6,6 +6,8 @@ Differences from the reference, all supersets:
   no checkpoint directory.
 * ``kvcache_block_size`` may be any multiple of 16 (the reference demands 256
   because of flash-attn; the HIP kernels take the block size at run time).
+* ``state_dict`` supplies an in-memory checkpoint (packed parameter names) instead
+  of safetensors files; with neither, synthetic weights are drawn from ``seed``.
 * ``quantization`` selects the weight format of the layer linears:
   ``None`` (dense), ``"w8a16"`` or ``"w4a16"``.
 """
@@ -54,6 +56,7 @@ class Config:
     num_kvcache_blocks: int = -1
     quantization: str | None = None
     seed: int = 0
+    state_dict: Any = None   # optional in-memory checkpoint keyed by the packed parameter names
 
     def __post_init__(self):
         assert self.kvcache_block_size % 16 == 0 and self.kvcache_block_size > 0

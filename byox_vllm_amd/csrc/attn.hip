@@ -1,0 +1,494 @@
+// Paged decode attention (flash-decoding) and causal variable-length prefill
+// attention for gfx950, one code path for both.
+//
+// Work decomposition.  A wavefront owns 16 "query columns" that share one KV
+// head: in decode the (up to 16) query heads of a GQA group for one sequence,
+// in prefill 16 consecutive query tokens of one head.  It walks its keys in
+// chunks of 32 tokens:
+//
+//   S^T[32 x 16] = K_chunk[32 x D] . Q^T[D x 16]      (2 x D/32 MFMA 16x16x32)
+//   online softmax down each column (column = lane & 15, so the running max,
+//   the row sum and the rescale factor are lane-local; one 2-step xor shuffle
+//   joins the four 16-lane groups for the max)
+//   O^T[D x 16] += V_chunk^T[D x 32] . P^T[32 x 16]   (D/16 MFMA 16x16x32)
+//
+// The S^T accumulator layout (column on the lane, four consecutive tokens in
+// the four registers) is already the B-operand layout of the second product if
+// k-slot (g, j) of that MFMA is taken to mean token 4g+j (j<4) / 16+4g+j-4
+// (j>=4), so P never leaves registers.  The V^T operand is built from 16-byte
+// row loads (lane (c, g) loads d = 8c..8c+7 of its 8 tokens) by an 8x8 16-bit
+// register transpose, which makes output register (m, r) hold
+// O[col][d = 8(4g + r) + m]: 8 consecutive d per (g, r) for one 16-byte store.
+// K and V go HBM -> VGPR directly: every byte is used once by one wavefront.
+//
+// Decode: grid (splits, Hkv, B), 4 wavefronts per workgroup; wavefront w of
+// split s takes chunks s*4+w, s*4+w+4*splits, ...; the 4 partial results are
+// merged through LDS and, when splits > 1, per-split partials (fp32 O, max,
+// sum) go to the workspace for a small combine kernel.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+
+template <int D> struct AttnGeom {
+  static constexpr int KS = D / 32;   // k-steps of the S^T product
+  static constexpr int NM = D / 16;   // MFMAs of the O^T product == d values per lane load
+};
+
+// One lane's view of where a 16-token tile lives.
+struct TileAddr {
+  int64_t row;   // first cache/packed row of the tile
+};
+
+template <typename T, int D>
+struct AttnState {
+  float m;                                   // running max (log2 domain), same in the 4 lanes of a column
+  float l;                                   // this lane's share of the row sum
+  f32x4 acc[AttnGeom<D>::NM];
+};
+
+// Loads for one 32-token chunk and the two MFMA products.
+//  k_base/v_base: pointer to element [row 0][this kv head][0]; row_stride in elements
+//  rows[2]: first row of tile 0 / tile 1 (wave-uniform)
+//  limit: number of visible keys for this lane's column; base: first token of the chunk
+template <typename T, int D, bool TAIL>
+__device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS],
+                                           const uint16_t* k_base, const uint16_t* v_base, int64_t row_stride,
+                                           const int64_t (&rows)[2], int64_t max_row, int base, int limit, int n_keys,
+                                           float scale2) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+
+  // ---- issue all loads of the chunk: K as A-operand fragments, V rows
+  frag_t kf[2][KS];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    int64_t krow = rows[tl] + c;
+    if (TAIL && krow > max_row) krow = max_row;   // packed keys: never read past the buffer
+    const uint16_t* kr = k_base + krow * row_stride + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[tl][ks] = *reinterpret_cast<const frag_t*>(kr + 32 * ks);
+  }
+  uint32_t vv[8][NM / 2];   // token j: NM consecutive d values starting at NM*c
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int off = (j < 4) ? (4 * g + j) : (4 * g + j - 4);
+    int64_t vrow = rows[j >> 2] + off;
+    if (TAIL && vrow > max_row) vrow = max_row;
+    const uint16_t* vr = v_base + vrow * row_stride + NM * c;
+    if constexpr (NM == 8) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(vr);
+      vv[j][0] = t[0]; vv[j][1] = t[1]; vv[j][2] = t[2]; vv[j][3] = t[3];
+    } else {
+      const u32x2 t = *reinterpret_cast<const u32x2*>(vr);
+      vv[j][0] = t[0]; vv[j][1] = t[1];
+    }
+  }
+
+  // ---- S^T = K . Q^T
+  f32x4 s[2];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl) {
+    s[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s[tl] = mfma16(kf[tl][ks], qf[ks], s[tl]);
+  }
+
+  // ---- online softmax, column-local
+  float cmax = -INFINITY;
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = base + 16 * tl + 4 * g + r;
+      float x = s[tl][r] * scale2;
+      x = (tok < limit) ? x : -INFINITY;
+      s[tl][r] = x;
+      cmax = fmaxf(cmax, x);
+    }
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+  const float m_new = fmaxf(st.m, cmax);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = (st.m == -INFINITY) ? 0.f : exp2f(st.m - m_use);
+  float psum = 0.f;
+  frag_t pf;
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = exp2f(s[tl][r] - m_use);
+      psum += p;
+      pf[tl * 4 + r] = (T)p;
+    }
+  st.m = m_new;
+  st.l = st.l * alpha + psum;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) st.acc[m] *= alpha;
+
+  // ---- V^T operand: 8 x NM transpose of 16-bit values held in registers
+  if (TAIL) {  // keys past the end may hold anything (even NaN bit patterns): zero them, 0 * NaN != 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tok = base + ((j < 4) ? (4 * g + j) : (16 + 4 * g + j - 4));
+      if (tok >= n_keys) {
+#pragma unroll
+        for (int e = 0; e < NM / 2; ++e) vv[j][e] = 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    u32x4 w;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const uint32_t a = vv[2 * jj][m >> 1], b = vv[2 * jj + 1][m >> 1];
+      w[jj] = (m & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    st.acc[m] = mfma16(__builtin_bit_cast(frag_t, w), pf, st.acc[m]);
+  }
+}
+
+// Row index (in units of cache rows) of the first token of the 16-token tile that starts at `tok`.
+__device__ __forceinline__ int64_t paged_tile_row(const int32_t* bt_row, int tok, int block_size) {
+  const int blk = tok / block_size;              // wave-uniform
+  const int off = tok - blk * block_size;
+  return (int64_t)bt_row[blk] * block_size + off;
+}
+
+// ------------------------------------------------------------------ decode
+template <typename T, int D>
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
+    const uint16_t* __restrict__ v_cache, const int32_t* __restrict__ block_tables, int bt_stride,
+    const int32_t* __restrict__ context_lens, uint16_t* __restrict__ out, int64_t out_stride,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int H, int Hkv, int block_size, float scale2,
+    int splits) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
+  __shared__ float s_acc[4][NM * 4][64];
+  __shared__ float s_m[4][16];
+  __shared__ float s_l[4][16];
+
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int G = H / Hkv;
+  const int n_keys = context_lens[b];
+  const int64_t row_stride = (int64_t)Hkv * D;
+  const uint16_t* k_base = k_cache + (int64_t)kvh * D;
+  const uint16_t* v_base = v_cache + (int64_t)kvh * D;
+  const int32_t* bt_row = block_tables + (int64_t)b * bt_stride;
+
+  // Q^T as the B operand: lane (c, g) holds q[head c][32 ks + 8 g ..+7]
+  frag_t qf[KS];
+  {
+    const bool live = c < G;
+    const uint16_t* qr = q + (int64_t)b * q_stride + (int64_t)(kvh * G + (live ? c : 0)) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(qr + 32 * ks);
+      if (!live) t = u32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(frag_t, t);
+    }
+  }
+
+  AttnState<T, D> st;
+  st.m = -INFINITY;
+  st.l = 0.f;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) st.acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_chunks = (n_keys + 31) >> 5;
+  const int stride_chunks = splits * 4;
+  for (int ch = split * 4 + wid; ch < n_chunks; ch += stride_chunks) {
+    const int base = ch << 5;
+    int64_t rows[2];
+    rows[0] = paged_tile_row(bt_row, base, block_size);
+    // a second tile that starts past the end re-reads tile 0 (masked anyway)
+    rows[1] = (base + 16 < n_keys) ? paged_tile_row(bt_row, base + 16, block_size) : rows[0];
+    if (base + 32 <= n_keys)
+      attn_chunk<T, D, false>(st, qf, k_base, v_base, row_stride, rows, INT64_MAX, base, n_keys, n_keys, scale2);
+    else
+      attn_chunk<T, D, true>(st, qf, k_base, v_base, row_stride, rows, INT64_MAX, base, n_keys, n_keys, scale2);
+  }
+
+  // ---- merge the 4 wavefronts of the workgroup
+  float l = st.l;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (g == 0) {
+    s_m[wid][c] = st.m;
+    s_l[wid][c] = l;
+  }
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_acc[wid][m * 4 + r][lane] = st.acc[m][r];
+  __syncthreads();
+
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) M = fmaxf(M, s_m[w][c]);
+  float f[4], L = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float mw = s_m[w][c];
+    f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
+    L += s_l[w][c] * f[w];
+  }
+  // wavefront `wid` finishes register r = wid of every m: d = NM*(4g + wid) + m, m = 0..NM-1 contiguous
+  float o[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += s_acc[w][m * 4 + wid][lane] * f[w];
+    o[m] = v;
+  }
+  if (c >= G) return;
+  const int head = kvh * G + c;
+  const int d0 = NM * (4 * g + wid);
+  if (splits == 1) {
+    const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+    uint16_t* dst = out + (int64_t)b * out_stride + (int64_t)head * D + d0;
+    if constexpr (NM == 8) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+      *reinterpret_cast<u32x4*>(dst) = w;
+    } else {
+      u32x2 w;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+      *reinterpret_cast<u32x2*>(dst) = w;
+    }
+  } else {
+    const int64_t slot = ((int64_t)b * H + head) * splits + split;
+    float* dst = part_o + slot * D + d0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) dst[m] = o[m];
+    if (g == 0 && wid == 0) {
+      part_ml[slot * 2] = M;
+      part_ml[slot * 2 + 1] = L;
+    }
+  }
+}
+
+// merge the per-split partials: one wavefront per (sequence, head)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_combine_kernel(const float* __restrict__ part_o,
+                                                             const float* __restrict__ part_ml,
+                                                             uint16_t* __restrict__ out, int64_t out_stride, int H,
+                                                             int splits, int64_t total) {
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= total) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = item / H;
+  const int head = (int)(item - b * H);
+  const float* ml = part_ml + item * splits * 2;
+  float M = -INFINITY;
+  for (int s = 0; s < splits; ++s) M = fmaxf(M, ml[2 * s]);
+  float L = 0.f;
+  constexpr int PER = D / 64;
+  float o[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) o[e] = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float ms = ml[2 * s];
+    const float f = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
+    L += ml[2 * s + 1] * f;
+    const float* po = part_o + (item * splits + s) * D + lane * PER;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) o[e] += po[e] * f;
+  }
+  const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+  uint16_t* dst = out + b * out_stride + (int64_t)head * D + lane * PER;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) dst[e] = f32_to_bits<T>(o[e] * inv);
+}
+
+// ------------------------------------------------------------------ prefill
+// grid (ceil(max_seqlen_q / 64), H, num_seqs); wavefront w of a workgroup owns
+// query tokens [64*bx + 16*w, +16) of one head of one sequence.
+template <typename T, int D, bool PAGED>
+__global__ __launch_bounds__(256) void prefill_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
+    const int32_t* __restrict__ block_tables, int bt_stride, uint16_t* __restrict__ out, int64_t out_stride, int H,
+    int Hkv, int block_size, float scale2) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int q0 = cu_q[seq], q_len = cu_q[seq + 1] - q0;
+  const int k0 = cu_k[seq], k_len = cu_k[seq + 1] - k0;
+  const int qt = blockIdx.x * 64 + wid * 16;   // first query of this wavefront's tile
+  if (qt >= q_len) return;
+  const int kvh = head / (H / Hkv);
+  const int qi = qt + c;
+  const bool live = qi < q_len;
+  // bottom-right aligned causal mask: query qi sees keys [0, k_len - q_len + qi]
+  const int limit = live ? (k_len - q_len + qi + 1) : 0;
+  int last_q = qt + 15;
+  if (last_q > q_len - 1) last_q = q_len - 1;
+  const int n_keys = k_len - q_len + last_q + 1;   // keys any column of the tile can see
+
+  frag_t qf[KS];
+  {
+    const uint16_t* qr = q + (int64_t)(q0 + (live ? qi : qt)) * q_stride + (int64_t)head * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(qr + 32 * ks);
+      if (!live) t = u32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(frag_t, t);
+    }
+  }
+  AttnState<T, D> st;
+  st.m = -INFINITY;
+  st.l = 0.f;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) st.acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t row_stride = PAGED ? (int64_t)Hkv * D : kv_stride;
+  const uint16_t* k_base = k + (int64_t)kvh * D;
+  const uint16_t* v_base = v + (int64_t)kvh * D;
+  const int32_t* bt_row = PAGED ? block_tables + (int64_t)seq * bt_stride : nullptr;
+  const int64_t max_row = PAGED ? INT64_MAX : (int64_t)k0 + k_len - 1;
+  const int n_chunks = (n_keys + 31) >> 5;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int base = ch << 5;
+    int64_t rows[2];
+    if (PAGED) {
+      rows[0] = paged_tile_row(bt_row, base, block_size);
+      rows[1] = (base + 16 < n_keys) ? paged_tile_row(bt_row, base + 16, block_size) : rows[0];
+    } else {
+      rows[0] = k0 + base;
+      rows[1] = k0 + base + 16;
+    }
+    // the causal diagonal is masked per token in both variants; TAIL additionally clamps rows and zeroes junk V
+    if (base + 32 <= n_keys)
+      attn_chunk<T, D, false>(st, qf, k_base, v_base, row_stride, rows, max_row, base, limit, n_keys, scale2);
+    else
+      attn_chunk<T, D, true>(st, qf, k_base, v_base, row_stride, rows, max_row, base, limit, n_keys, scale2);
+  }
+  float l = st.l;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (!live) return;
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  uint16_t* orow = out + (int64_t)(q0 + qi) * out_stride + (int64_t)head * D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint16_t* dst = orow + NM * (4 * g + r);
+    if constexpr (NM == 8) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = pack2<T>(st.acc[2 * e][r] * inv, st.acc[2 * e + 1][r] * inv);
+      *reinterpret_cast<u32x4*>(dst) = w;
+    } else {
+      u32x2 w;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) w[e] = pack2<T>(st.acc[2 * e][r] * inv, st.acc[2 * e + 1][r] * inv);
+      *reinterpret_cast<u32x2*>(dst) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
+  if (B <= 0 || Hkv <= 0) return 1;
+  int64_t groups = (int64_t)B * Hkv;
+  int splits = (int)((1024 + groups - 1) / groups);          // aim at >= 1024 workgroups of 4 wavefronts
+  int by_len = (max_context + 127) / 128;                     // at least one 32-token chunk per wavefront
+  if (splits > by_len) splits = by_len;
+  if (splits > 32) splits = 32;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+extern "C" size_t nv_paged_attn_decode_workspace_bytes(int B, int H, int D, int num_splits) {
+  if (num_splits <= 1) return 0;
+  return (size_t)B * H * num_splits * (D + 2) * sizeof(float);
+}
+
+extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                                    const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
+                                    void* out, int64_t out_row_stride, void* workspace, size_t workspace_bytes, int B,
+                                    int H, int Hkv, int D, int block_size, float scale, int num_splits, int dtype,
+                                    nv_stream_t stream) {
+  NV_CHECK_ARG(q && k_cache && v_cache && block_tables && context_lens && out, "nv_paged_attn_decode: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_paged_attn_decode: bad dtype %d", dtype);
+  NV_CHECK_ARG(D == 64 || D == 128, "nv_paged_attn_decode: head_dim %d not in {64, 128}", D);
+  NV_CHECK_ARG(H > 0 && Hkv > 0 && H % Hkv == 0 && H / Hkv <= 16, "nv_paged_attn_decode: H=%d Hkv=%d (group must be <= 16)", H, Hkv);
+  NV_CHECK_ARG(block_size > 0 && block_size % 16 == 0, "nv_paged_attn_decode: block_size=%d must be a multiple of 16", block_size);
+  NV_CHECK_ARG(q_row_stride % 8 == 0 && out_row_stride % 8 == 0, "nv_paged_attn_decode: row strides must be multiples of 8");
+  NV_CHECK_ARG(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out) % 16 == 0,
+               "nv_paged_attn_decode: pointers must be 16-byte aligned");
+  NV_CHECK_ARG(B >= 0 && B <= 65535 && Hkv <= 65535, "nv_paged_attn_decode: B=%d too large for one launch", B);
+  if (B == 0) return NV_OK;
+  if (num_splits <= 0) num_splits = 1;
+  const size_t need = nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits);
+  NV_CHECK_ARG(need == 0 || (workspace && workspace_bytes >= need),
+               "nv_paged_attn_decode: workspace %zu bytes < %zu needed", workspace_bytes, need);
+  float* part_o = (float*)workspace;
+  float* part_ml = part_o ? part_o + (size_t)B * H * num_splits * D : nullptr;
+  const float scale2 = scale * LOG2E;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(num_splits, Hkv, B), block(256);
+#define LAUNCH_DEC(TT, DD)                                                                                           \
+  paged_decode_kernel<TT, DD><<<grid, block, 0, s>>>((const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache,    \
+                                                     (const uint16_t*)v_cache, block_tables, bt_stride, context_lens, \
+                                                     (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv,        \
+                                                     block_size, scale2, num_splits)
+  if (dtype == NV_BF16) { if (D == 128) LAUNCH_DEC(bf16_t, 128); else LAUNCH_DEC(bf16_t, 64); }
+  else                  { if (D == 128) LAUNCH_DEC(f16_t, 128); else LAUNCH_DEC(f16_t, 64); }
+#undef LAUNCH_DEC
+  NV_CHECK_LAUNCH();
+  if (num_splits > 1) {
+    const int64_t total = (int64_t)B * H;
+    dim3 cgrid((unsigned)((total + 3) / 4));
+#define LAUNCH_CMB(TT, DD)                                                                                      \
+  decode_combine_kernel<TT, DD><<<cgrid, block, 0, s>>>(part_o, part_ml, (uint16_t*)out, out_row_stride, H,     \
+                                                        num_splits, total)
+    if (dtype == NV_BF16) { if (D == 128) LAUNCH_CMB(bf16_t, 128); else LAUNCH_CMB(bf16_t, 64); }
+    else                  { if (D == 128) LAUNCH_CMB(f16_t, 128); else LAUNCH_CMB(f16_t, 64); }
+#undef LAUNCH_CMB
+    NV_CHECK_LAUNCH();
+  }
+  return NV_OK;
+}
+
+extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* k, const void* v,
+                               int64_t kv_row_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                               const int32_t* block_tables, int bt_stride, void* out, int64_t out_row_stride,
+                               int num_seqs, int max_seqlen_q, int H, int Hkv, int D, int block_size, float scale,
+                               int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(q && k && v && cu_seqlens_q && cu_seqlens_k && out, "nv_attn_prefill: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_attn_prefill: bad dtype %d", dtype);
+  NV_CHECK_ARG(D == 64 || D == 128, "nv_attn_prefill: head_dim %d not in {64, 128}", D);
+  NV_CHECK_ARG(H > 0 && Hkv > 0 && H % Hkv == 0, "nv_attn_prefill: H=%d Hkv=%d", H, Hkv);
+  NV_CHECK_ARG(!block_tables || (block_size > 0 && block_size % 16 == 0), "nv_attn_prefill: block_size=%d must be a multiple of 16", block_size);
+  NV_CHECK_ARG(q_row_stride % 8 == 0 && out_row_stride % 8 == 0 && kv_row_stride % 8 == 0, "nv_attn_prefill: row strides must be multiples of 8");
+  NV_CHECK_ARG(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16 == 0, "nv_attn_prefill: pointers must be 16-byte aligned");
+  NV_CHECK_ARG(num_seqs >= 0 && num_seqs <= 65535 && H <= 65535, "nv_attn_prefill: too many sequences for one launch");
+  if (num_seqs == 0 || max_seqlen_q <= 0) return NV_OK;
+  const float scale2 = scale * LOG2E;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((max_seqlen_q + 63) / 64, H, num_seqs), block(256);
+#define LAUNCH_PRE(TT, DD, PP)                                                                                        \
+  prefill_kernel<TT, DD, PP><<<grid, block, 0, s>>>((const uint16_t*)q, q_row_stride, (const uint16_t*)k,            \
+                                                    (const uint16_t*)v, kv_row_stride, cu_seqlens_q, cu_seqlens_k,   \
+                                                    block_tables, bt_stride, (uint16_t*)out, out_row_stride, H, Hkv, \
+                                                    block_size, scale2)
+  const bool paged = block_tables != nullptr;
+  if (dtype == NV_BF16) {
+    if (D == 128) { if (paged) LAUNCH_PRE(bf16_t, 128, true); else LAUNCH_PRE(bf16_t, 128, false); }
+    else          { if (paged) LAUNCH_PRE(bf16_t, 64, true); else LAUNCH_PRE(bf16_t, 64, false); }
+  } else {
+    if (D == 128) { if (paged) LAUNCH_PRE(f16_t, 128, true); else LAUNCH_PRE(f16_t, 128, false); }
+    else          { if (paged) LAUNCH_PRE(f16_t, 64, true); else LAUNCH_PRE(f16_t, 64, false); }
+  }
+#undef LAUNCH_PRE
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}

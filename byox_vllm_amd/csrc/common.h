@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 kernels behind the nv_* C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nv_hip.h"
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define NV_WAVE 64
+
+// Last error text, readable through nv_last_error().
+void nv_set_error(const char* fmt, ...);
+
+#define NV_CHECK_ARG(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      nv_set_error(__VA_ARGS__);         \
+      return NV_ERR_INVALID;             \
+    }                                    \
+  } while (0)
+
+#define NV_CHECK_LAUNCH()                                              \
+  do {                                                                 \
+    hipError_t e_ = hipGetLastError();                                 \
+    if (e_ != hipSuccess) {                                            \
+      nv_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+      return NV_ERR_LAUNCH;                                            \
+    }                                                                  \
+  } while (0)
+
+template <typename T> struct VecOf;
+template <> struct VecOf<bf16_t> { typedef bf16x8 x8; };
+template <> struct VecOf<f16_t> { typedef f16x8 x8; };
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// 16-bit storage <-> float.  The 16-bit payload travels as raw bits in uint16/uint32.
+template <typename T> __device__ __forceinline__ float bits_to_f32(uint16_t b);
+template <> __device__ __forceinline__ float bits_to_f32<bf16_t>(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+template <> __device__ __forceinline__ float bits_to_f32<f16_t>(uint16_t b) {
+  return (float)__builtin_bit_cast(f16_t, b);
+}
+template <typename T> __device__ __forceinline__ uint16_t f32_to_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (T)f);   // round to nearest even
+}
+// low / high half of a packed pair
+template <typename T> __device__ __forceinline__ float lo_f32(uint32_t w) { return bits_to_f32<T>((uint16_t)(w & 0xffffu)); }
+template <typename T> __device__ __forceinline__ float hi_f32(uint32_t w) { return bits_to_f32<T>((uint16_t)(w >> 16)); }
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f32_to_bits<T>(lo) | ((uint32_t)f32_to_bits<T>(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,215 @@
+// Small memory-bound kernels of the decode step: SiLU-and-multiply, embedding
+// row gather, Gumbel-max / argmax sampler, graph-replay input staging; plus the
+// library's version and error-string entry points.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void nv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* nv_last_error(void) { return g_err; }
+extern "C" int nv_version(void) { return 100; }
+
+// ---------------------------------------------------------------- silu * up
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                       int64_t T_, int I) {
+  const int nvec = I >> 3;
+  const int64_t total = T_ * nvec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = v / nvec;
+    const int c = (int)(v - t * nvec);
+    const u32x4 g = reinterpret_cast<const u32x4*>(x + t * 2 * I)[c];
+    const u32x4 u = reinterpret_cast<const u32x4*>(x + t * 2 * I + I)[c];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = lo_f32<T>(g[j]), g1 = hi_f32<T>(g[j]);
+      // silu rounds to the model dtype, then the product rounds again (eager semantics)
+      const float s0 = bits_to_f32<T>(f32_to_bits<T>(g0 / (1.0f + expf(-g0))));
+      const float s1 = bits_to_f32<T>(f32_to_bits<T>(g1 / (1.0f + expf(-g1))));
+      o[j] = pack2<T>(s0 * lo_f32<T>(u[j]), s1 * hi_f32<T>(u[j]));
+    }
+    reinterpret_cast<u32x4*>(out + t * I)[c] = o;
+  }
+}
+
+extern "C" int nv_silu_mul(const void* x, void* out, int64_t T, int I, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(x && out, "nv_silu_mul: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_silu_mul: bad dtype %d", dtype);
+  NV_CHECK_ARG(I > 0 && I % 8 == 0, "nv_silu_mul: I=%d must be a multiple of 8", I);
+  NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)out) % 16 == 0, "nv_silu_mul: pointers must be 16-byte aligned");
+  if (T == 0) return NV_OK;
+  const int64_t total = T * (I / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NV_BF16)
+    silu_mul_kernel<bf16_t><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const uint16_t*)x, (uint16_t*)out, T, I);
+  else
+    silu_mul_kernel<f16_t><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const uint16_t*)x, (uint16_t*)out, T, I);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
+
+// ---------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const uint16_t* __restrict__ w,
+                                                    uint16_t* __restrict__ out, int64_t T_, int hidden,
+                                                    int64_t vocab_start, int64_t vocab_local) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T_) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t id = ids[t] - vocab_start;
+  const bool ok = id >= 0 && id < vocab_local;
+  const u32x4* src = reinterpret_cast<const u32x4*>(w + (ok ? id : 0) * hidden);
+  u32x4* dst = reinterpret_cast<u32x4*>(out + t * hidden);
+  const u32x4 zero = {0, 0, 0, 0};
+  for (int i = lane; i < (hidden >> 3); i += 64) dst[i] = ok ? src[i] : zero;
+}
+
+extern "C" int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int hidden, int64_t vocab_start,
+                        int64_t vocab_local, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(ids && weight && out, "nv_embed: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_embed: bad dtype %d", dtype);
+  NV_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "nv_embed: hidden=%d must be a multiple of 8", hidden);
+  NV_CHECK_ARG(((uintptr_t)weight | (uintptr_t)out) % 16 == 0, "nv_embed: pointers must be 16-byte aligned");
+  if (T == 0) return NV_OK;
+  embed_kernel<<<dim3((unsigned)((T + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+      ids, (const uint16_t*)weight, (uint16_t*)out, T, hidden, vocab_start, vocab_local);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
+
+// ---------------------------------------------------------------- sampler
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+struct Best {
+  float v;
+  int i;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sample_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                      const float* __restrict__ temps, const float* __restrict__ noise,
+                                                      int64_t* __restrict__ tokens, int V, uint64_t seed) {
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  const uint16_t* row = logits + (int64_t)b * row_stride;
+  const float temp = temps[b];
+  const bool greedy = temp == 0.0f;
+  float mx = -INFINITY;
+  if (!greedy) {  // row max of logits / T
+    for (int v = tid; v < V; v += blockDim.x) mx = fmaxf(mx, bits_to_f32<T>(row[v]) / temp);
+    mx = wave_max(mx);
+    if (lane == 0) s_val[wid] = mx;
+    __syncthreads();
+    mx = s_val[0];
+    for (int w = 1; w < nw; ++w) mx = fmaxf(mx, s_val[w]);
+    __syncthreads();
+  }
+  Best best = {-INFINITY, 0x7fffffff};
+  for (int v = tid; v < V; v += blockDim.x) {
+    const float l = bits_to_f32<T>(row[v]);
+    float score;
+    if (greedy) {
+      score = l;
+    } else {
+      float e;
+      if (noise) {
+        e = noise[(int64_t)b * V + v];
+      } else {  // Exp(1) = -log(U), U uniform in (0, 1]
+        const uint32_t r = mix32(seed ^ ((uint64_t)b << 32) ^ (uint64_t)v);
+        e = -logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f));
+      }
+      // softmax's normaliser is common to the row and cannot change the argmax
+      score = expf(l / temp - mx) / fmaxf(e, 1e-10f);
+    }
+    best = better(best, Best{score, v});
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best other = {__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
+    best = better(best, other);
+  }
+  if (lane == 0) {
+    s_val[wid] = best.v;
+    s_idx[wid] = best.i;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < nw; ++w) best = better(best, Best{s_val[w], s_idx[w]});
+    tokens[b] = best.i;
+  }
+}
+
+extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
+                         int64_t* tokens, int B, int V, uint64_t seed, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(logits && temperatures && tokens, "nv_sample: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_sample: bad dtype %d", dtype);
+  NV_CHECK_ARG(V > 0 && B >= 0, "nv_sample: bad shape B=%d V=%d", B, V);
+  if (B == 0) return NV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NV_BF16)
+    sample_kernel<bf16_t><<<dim3(B), dim3(1024), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
+                                                         noise, tokens, V, seed);
+  else
+    sample_kernel<f16_t><<<dim3(B), dim3(1024), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, noise,
+                                                        tokens, V, seed);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
+
+// ---------------------------------------------------------------- graph input staging
+__global__ __launch_bounds__(256) void stage_kernel(const int64_t* ids, const int64_t* pos, const int32_t* slots,
+                                                    const int32_t* ctx, const int32_t* bt, int bt_cols, int64_t* g_ids,
+                                                    int64_t* g_pos, int32_t* g_slots, int32_t* g_ctx, int32_t* g_bt,
+                                                    int g_bt_cols, int bs, int padded) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  for (int i = tid; i < padded; i += nthr) {
+    const bool live = i < bs;
+    g_ids[i] = live ? ids[i] : 0;
+    g_pos[i] = live ? pos[i] : 0;
+    g_slots[i] = live ? slots[i] : -1;
+    g_ctx[i] = live ? ctx[i] : 0;
+  }
+  for (int i = tid; i < bs * bt_cols; i += nthr) {
+    const int r = i / bt_cols, c = i - r * bt_cols;
+    g_bt[r * g_bt_cols + c] = bt[i];
+  }
+}
+
+extern "C" int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positions, const int32_t* slots,
+                                      const int32_t* context_lens, const int32_t* block_tables, int bt_cols,
+                                      int64_t* g_ids, int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
+                                      int32_t* g_block_tables, int g_bt_cols, int bs, int padded_bs,
+                                      nv_stream_t stream) {
+  NV_CHECK_ARG(ids && positions && slots && context_lens && block_tables, "nv_stage_decode_inputs: null input");
+  NV_CHECK_ARG(g_ids && g_positions && g_slots && g_context_lens && g_block_tables, "nv_stage_decode_inputs: null buffer");
+  NV_CHECK_ARG(bs >= 0 && padded_bs >= bs && bt_cols >= 0 && bt_cols <= g_bt_cols,
+               "nv_stage_decode_inputs: bs=%d padded=%d bt_cols=%d g_bt_cols=%d", bs, padded_bs, bt_cols, g_bt_cols);
+  if (padded_bs == 0) return NV_OK;
+  int work = bs * bt_cols > padded_bs ? bs * bt_cols : padded_bs;
+  int blocks = (work + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  stage_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(ids, positions, slots, context_lens, block_tables,
+                                                                    bt_cols, g_ids, g_positions, g_slots,
+                                                                    g_context_lens, g_block_tables, g_bt_cols, bs,
+                                                                    padded_bs);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}

@@ -1,0 +1,100 @@
+// RMSNorm and fused residual-add RMSNorm for gfx950.
+// One 64-lane wavefront owns one row: 16-byte loads (8 elements per lane per
+// step), an xor-shuffle reduction of the sum of squares, 16-byte stores.  The
+// rows are a few KB, so the second pass over the row is served by the CU's L1.
+#include "common.h"
+
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const uint16_t* res,
+                                                      const uint16_t* __restrict__ w, uint16_t* out,
+                                                      uint16_t* res_out, int64_t rows, int hidden,
+                                                      int64_t x_stride, int64_t out_stride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = hidden >> 3;
+  const u32x4* xv = reinterpret_cast<const u32x4*>(x + row * x_stride);
+  const u32x4* rv = ADD ? reinterpret_cast<const u32x4*>(res + row * x_stride) : nullptr;
+  u32x4* ro = ADD ? reinterpret_cast<u32x4*>(res_out + row * x_stride) : nullptr;
+  const u32x4* wv = reinterpret_cast<const u32x4*>(w);
+  u32x4* ov = reinterpret_cast<u32x4*>(out + row * out_stride);
+
+  float ss = 0.f;
+  for (int i = lane; i < nvec; i += 64) {
+    u32x4 a = xv[i];
+    u32x4 b = {0, 0, 0, 0};
+    if (ADD) b = rv[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = lo_f32<T>(a[j]), hi = hi_f32<T>(a[j]);
+      if (ADD) {
+        lo = lo + lo_f32<T>(b[j]);
+        hi = hi + hi_f32<T>(b[j]);
+      }
+      ss = fmaf(lo, lo, ss);
+      ss = fmaf(hi, hi, ss);
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+
+  for (int i = lane; i < nvec; i += 64) {
+    u32x4 a = xv[i];
+    u32x4 b = {0, 0, 0, 0};
+    if (ADD) b = rv[i];
+    u32x4 ww = wv[i];
+    u32x4 o, r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = lo_f32<T>(a[j]), hi = hi_f32<T>(a[j]);
+      if (ADD) {
+        lo = lo + lo_f32<T>(b[j]);
+        hi = hi + hi_f32<T>(b[j]);
+        r[j] = pack2<T>(lo, hi);
+      }
+      // normalise in fp32, round to the model dtype, THEN scale by the weight
+      const float nlo = bits_to_f32<T>(f32_to_bits<T>(lo * inv));
+      const float nhi = bits_to_f32<T>(f32_to_bits<T>(hi * inv));
+      o[j] = pack2<T>(nlo * lo_f32<T>(ww[j]), nhi * hi_f32<T>(ww[j]));
+    }
+    if (ADD) ro[i] = r;
+    ov[i] = o;
+  }
+}
+
+template <bool ADD>
+static int launch_norm(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
+                       int hidden, int64_t xs, int64_t os, float eps, int dtype, hipStream_t s) {
+  if (rows == 0) return NV_OK;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == NV_BF16)
+    rmsnorm_kernel<bf16_t, ADD><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w,
+                                                       (uint16_t*)out, (uint16_t*)res_out, rows, hidden, xs, os, eps);
+  else
+    rmsnorm_kernel<f16_t, ADD><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w,
+                                                      (uint16_t*)out, (uint16_t*)res_out, rows, hidden, xs, os, eps);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
+
+extern "C" int nv_rmsnorm(const void* x, const void* weight, void* out, int64_t rows, int hidden, int64_t x_row_stride,
+                          int64_t out_row_stride, float eps, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(x && weight && out, "nv_rmsnorm: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_rmsnorm: bad dtype %d", dtype);
+  NV_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "nv_rmsnorm: hidden=%d must be a positive multiple of 8", hidden);
+  NV_CHECK_ARG(x_row_stride % 8 == 0 && out_row_stride % 8 == 0, "nv_rmsnorm: row strides must be multiples of 8");
+  NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)out | (uintptr_t)weight) % 16 == 0, "nv_rmsnorm: pointers must be 16-byte aligned");
+  return launch_norm<false>(x, nullptr, weight, out, nullptr, rows, hidden, x_row_stride, out_row_stride, eps, dtype,
+                            (hipStream_t)stream);
+}
+
+extern "C" int nv_add_rmsnorm(const void* x, const void* residual, const void* weight, void* out, void* residual_out,
+                              int64_t rows, int hidden, float eps, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(x && residual && weight && out && residual_out, "nv_add_rmsnorm: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_add_rmsnorm: bad dtype %d", dtype);
+  NV_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "nv_add_rmsnorm: hidden=%d must be a positive multiple of 8", hidden);
+  NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)out | (uintptr_t)weight | (uintptr_t)residual | (uintptr_t)residual_out) % 16 == 0,
+               "nv_add_rmsnorm: pointers must be 16-byte aligned");
+  return launch_norm<true>(x, residual, weight, out, residual_out, rows, hidden, hidden, hidden, eps, dtype,
+                           (hipStream_t)stream);
+}

@@ -1,0 +1,319 @@
+"""Per-rank executor of the decode hot path (interface of nanovllm/engine/model_runner.py:17-297).
+
+``run(seqs, is_prefill)`` = prepare integer metadata on the host -> one forward
+pass on the HIP kernels -> sample.  Decode steps replay a hipGraph captured per
+padded batch size; prefill runs eagerly.  With tensor parallelism rank 0 ships
+the PREPARED integer arrays of the step (not pickled Sequence objects) to the
+other ranks through shared memory, so the control message stays a few KB at
+batch 512.
+"""
+
+import pickle
+from multiprocessing.shared_memory import SharedMemory
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from byox_vllm_amd import kernels
+from byox_vllm_amd.engine.sequence import Sequence
+from byox_vllm_amd.layers.sampler import Sampler
+from byox_vllm_amd.models.qwen3 import Qwen3ForCausalLM
+from byox_vllm_amd.utils.context import get_context, reset_context, set_context
+from byox_vllm_amd.utils.loader import init_random_weights, load_model
+from byox_vllm_amd.utils.logging import logger
+
+SHM_NAME = "byox_vllm_amd"
+SHM_BYTES = 1 << 22
+MAX_GRAPH_BS = 512
+
+
+def graph_batch_sizes(max_bs: int) -> list[int]:
+    """Padded batch sizes a decode graph is captured for (model_runner.py:269)."""
+    return [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+
+
+class ModelRunner:
+    def __init__(self, config, rank: int, event):
+        self.config = config
+        hf_config = config.hf_config
+        self.block_size = config.kvcache_block_size
+        self.enforce_eager = config.enforce_eager
+        self.world_size = config.tensor_parallel_size
+        self.rank = rank
+        self.event = event
+        if not torch.cuda.is_available():
+            raise RuntimeError("ModelRunner needs an MI355X: byox_vllm_amd has no CPU compute path")
+
+        self._own_pg = False
+        if self.world_size > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl", "tcp://127.0.0.1:2333", world_size=self.world_size, rank=rank)
+            self._own_pg = True
+        local = rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        default_dtype = torch.get_default_dtype()
+        torch.set_default_dtype(hf_config.dtype)
+        torch.set_default_device(self.device)
+        try:
+            self.model = Qwen3ForCausalLM(hf_config)
+            self._load_weights()
+            self.model.finalize(config.quantization)
+            self.sampler = Sampler(seed=config.seed)
+            self._warmup_model()
+            self._allocate_kv_cache()
+            if not self.enforce_eager:
+                self._capture_graphs()
+        finally:
+            torch.set_default_device("cpu")
+            torch.set_default_dtype(default_dtype)
+
+        if self.world_size > 1 and event is not None:
+            if rank == 0:
+                self.shm = SharedMemory(name=SHM_NAME, create=True, size=SHM_BYTES)
+                dist.barrier()
+            else:
+                dist.barrier()
+                self.shm = SharedMemory(name=SHM_NAME)
+                self._loop()
+
+    # ------------------------------------------------------------------ weights
+    def _load_weights(self):
+        import glob
+        import os
+        path = self.config.model
+        if self.config.state_dict is not None:
+            from byox_vllm_amd.utils.loader import load_state_dict_packed
+            load_state_dict_packed(self.model, self.config.state_dict, self.config.hf_config)
+        elif isinstance(path, str) and os.path.isdir(path) and glob.glob(os.path.join(path, "*.safetensors")):
+            load_model(self.model, path)
+        else:
+            logger.info("no safetensors under %r: drawing synthetic weights (seed %d)", path, self.config.seed)
+            init_random_weights(self.model, self.config.seed)
+
+    # ------------------------------------------------------------------ RPC (tensor parallel)
+    def call(self, method_name, *args):
+        if method_name == "run" and self.world_size > 1:
+            seqs, is_prefill = args
+            step = self._prepare_step(seqs, is_prefill)
+            if self.rank == 0 and getattr(self, "shm", None) is not None:
+                self._write_shm("run_step", step)
+            return self.run_step(step)
+        if self.world_size > 1 and self.rank == 0 and getattr(self, "shm", None) is not None:
+            self._write_shm(method_name, *args)
+        return getattr(self, method_name)(*args)
+
+    def _loop(self):
+        while True:
+            method_name, args = self._read_shm()
+            getattr(self, method_name)(*args)
+            if method_name == "exit":
+                break
+
+    def _read_shm(self):
+        assert self.world_size > 1 and self.rank > 0
+        self.event.wait()
+        n = int.from_bytes(self.shm.buf[0:4], "little")
+        method_name, *args = pickle.loads(self.shm.buf[4: n + 4])
+        self.event.clear()
+        return method_name, args
+
+    def _write_shm(self, method_name, *args):
+        assert self.world_size > 1 and self.rank == 0
+        data = pickle.dumps([method_name, *args])
+        n = len(data)
+        assert n + 4 <= self.shm.size, f"control message of {n} bytes exceeds the {self.shm.size}-byte channel"
+        self.shm.buf[0:4] = n.to_bytes(4, "little")
+        self.shm.buf[4: n + 4] = data
+        for event in self.event:
+            event.set()
+
+    def exit(self):
+        if self.world_size > 1 and getattr(self, "shm", None) is not None:
+            self.shm.close()
+            dist.barrier()
+            if self.rank == 0:
+                self.shm.unlink()
+        if not self.enforce_eager:
+            self.graphs, self.graph_pool = {}, None
+        torch.cuda.synchronize()
+        if self._own_pg:
+            dist.destroy_process_group()
+
+    # ------------------------------------------------------------------ the step
+    def run(self, seqs: list[Sequence], is_prefill: bool) -> list[int] | None:
+        input_ids, positions = self._prepare_prefill(seqs) if is_prefill else self._prepare_decode(seqs)
+        temperatures = self._prepare_sample(seqs) if self.rank == 0 else None
+        logits = self._run_model(input_ids, positions, is_prefill)
+        token_ids = self.sampler(logits, temperatures).tolist() if self.rank == 0 else None
+        reset_context()
+        return token_ids
+
+    def _prepare_step(self, seqs, is_prefill) -> dict:
+        """Host integers of one step as numpy arrays: the whole tensor-parallel control message."""
+        input_ids, positions = self._prepare_prefill(seqs, device="cpu") if is_prefill else self._prepare_decode(seqs, device="cpu")
+        ctx = get_context()
+        step = {"is_prefill": is_prefill, "input_ids": input_ids.numpy(), "positions": positions.numpy(),
+                "max_seqlen_q": ctx.max_seqlen_q, "max_seqlen_k": ctx.max_seqlen_k,
+                "temperatures": np.array([s.temperature for s in seqs], dtype=np.float32)}
+        for key in ("cu_seqlens_q", "cu_seqlens_k", "slot_mapping", "context_lens", "block_tables"):
+            t = getattr(ctx, key)
+            step[key] = None if t is None else t.numpy()
+        reset_context()
+        return step
+
+    def run_step(self, step: dict):
+        dev = lambda a: None if a is None else self._to_device(torch.from_numpy(a))  # noqa: E731
+        set_context(step["is_prefill"], dev(step["cu_seqlens_q"]), dev(step["cu_seqlens_k"]), step["max_seqlen_q"],
+                    step["max_seqlen_k"], dev(step["slot_mapping"]), dev(step["context_lens"]), dev(step["block_tables"]))
+        logits = self._run_model(dev(step["input_ids"]), dev(step["positions"]), step["is_prefill"])
+        token_ids = None
+        if self.rank == 0:
+            token_ids = self.sampler(logits, dev(step["temperatures"])).tolist()
+        reset_context()
+        return token_ids
+
+    # ------------------------------------------------------------------ host -> device metadata
+    def _to_device(self, t: torch.Tensor, device=None) -> torch.Tensor:
+        device = device if device is not None else getattr(self, "device", None)
+        if device is None:
+            device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        if torch.device(device).type == "cpu":
+            return t
+        return t.pin_memory().to(device, non_blocking=True)
+
+    def _prepare_block_tables(self, seqs: list[Sequence], device=None):
+        width = max(len(seq.block_table) for seq in seqs)
+        table = np.full((len(seqs), width), -1, dtype=np.int32)
+        for i, seq in enumerate(seqs):
+            table[i, : len(seq.block_table)] = seq.block_table
+        return self._to_device(torch.from_numpy(table), device)
+
+    def _prepare_prefill(self, seqs: list[Sequence], device=None):
+        bs = self.block_size
+        input_ids, positions, slot_mapping = [], [], []
+        cu_q, cu_k = [0], [0]
+        max_q = max_k = 0
+        for seq in seqs:
+            n, cached = len(seq), seq.num_cached_tokens
+            input_ids.extend(seq[cached:])
+            positions.extend(range(cached, n))
+            cu_q.append(cu_q[-1] + n - cached)
+            cu_k.append(cu_k[-1] + n)
+            max_q, max_k = max(max_q, n - cached), max(max_k, n)
+            if not seq.block_table:  # warmup sequences own no blocks
+                continue
+            last = seq.num_blocks - 1
+            for i in range(seq.num_cached_blocks, seq.num_blocks):
+                start = seq.block_table[i] * bs
+                slot_mapping.extend(range(start, start + (bs if i != last else seq.last_block_num_tokens)))
+        block_tables = self._prepare_block_tables(seqs, device) if cu_k[-1] > cu_q[-1] else None  # prefix hit
+        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt), device)  # noqa: E731
+        set_context(True, to(cu_q, torch.int32), to(cu_k, torch.int32), max_q, max_k,
+                    to(slot_mapping, torch.int32), None, block_tables)
+        return to(input_ids, torch.int64), to(positions, torch.int64)
+
+    def _prepare_decode(self, seqs: list[Sequence], device=None):
+        bs = self.block_size
+        input_ids = [seq.last_token for seq in seqs]
+        positions = [len(seq) - 1 for seq in seqs]
+        context_lens = [len(seq) for seq in seqs]
+        slot_mapping = [seq.block_table[-1] * bs + seq.last_block_num_tokens - 1 for seq in seqs]
+        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt), device)  # noqa: E731
+        slot_t, ctx_t = to(slot_mapping, torch.int32), to(context_lens, torch.int32)
+        block_tables = self._prepare_block_tables(seqs) if device is None else self._prepare_block_tables(seqs, device)
+        set_context(False, slot_mapping=slot_t, context_lens=ctx_t, block_tables=block_tables)
+        return to(input_ids, torch.int64), to(positions, torch.int64)
+
+    def _prepare_sample(self, seqs: list[Sequence]):
+        return self._to_device(torch.tensor([seq.temperature for seq in seqs], dtype=torch.float32))
+
+    # ------------------------------------------------------------------ forward
+    @torch.inference_mode()
+    def _run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool):
+        bs = input_ids.size(0)
+        if is_prefill or self.enforce_eager or bs > self.max_graph_bs:
+            if not is_prefill:
+                self._set_decode_splits(bs)
+            return self.model.compute_logits(self.model(input_ids, positions))
+        context = get_context()
+        padded = next(x for x in self.graph_bs if x >= bs)
+        g = self.graph_vars
+        g["padded_bs"] = padded
+        kernels.stage_decode_inputs(input_ids, positions, context.slot_mapping, context.context_lens,
+                                    context.block_tables.contiguous(), g)
+        self.graphs[padded].replay()
+        return self.model.compute_logits(g["outputs"][:bs])
+
+    def _set_decode_splits(self, bs: int) -> None:
+        hkv = self.model.model.layers[0].self_attn.num_kv_heads
+        splits = kernels.pick_decode_splits(bs, hkv, self.config.max_model_len)
+        for layer in self.model.model.layers:
+            layer.self_attn.attn.decode_splits = splits
+
+    def _warmup_model(self):
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        max_tokens, max_len = self.config.max_num_batched_tokens, self.config.max_model_len
+        num_seqs = max(1, min(max_tokens // max_len, self.config.max_num_seqs))
+        seqs = [Sequence([0] * max_len, self.block_size) for _ in range(num_seqs)]
+        self.run(seqs, True)
+        torch.cuda.empty_cache()
+
+    def _allocate_kv_cache(self):
+        config, hf = self.config, self.config.hf_config
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        block_bytes = 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * head_dim * hf.dtype.itemsize
+        if config.num_kvcache_blocks <= 0:
+            free, total = torch.cuda.mem_get_info()
+            stats = torch.cuda.memory_stats()
+            peak, current = stats["allocated_bytes.all.peak"], stats["allocated_bytes.all.current"]
+            config.num_kvcache_blocks = int(total * config.gpu_memory_utilization - (total - free) - peak + current) // block_bytes
+        assert config.num_kvcache_blocks > 0
+        # [2, L, NB, block, Hkv, D]: layer l reads kv_cache[0, l] / kv_cache[1, l], as the reference binds them
+        self.kv_cache = torch.zeros(2, hf.num_hidden_layers, config.num_kvcache_blocks, self.block_size,
+                                    num_kv_heads, head_dim, dtype=hf.dtype, device=self.device)
+        layer_id = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = self.kv_cache[0, layer_id]
+                module.v_cache = self.kv_cache[1, layer_id]
+                layer_id += 1
+
+    @torch.inference_mode()
+    def _capture_graphs(self):
+        """Capture one hipGraph of the decode forward per padded batch size, largest first, sharing one pool."""
+        config, hf = self.config, self.config.hf_config
+        max_bs = min(config.max_num_seqs, MAX_GRAPH_BS)
+        max_blocks = (config.max_model_len + self.block_size - 1) // self.block_size
+        dev = self.device
+        g = dict(
+            input_ids=torch.zeros(max_bs, dtype=torch.int64, device=dev),
+            positions=torch.zeros(max_bs, dtype=torch.int64, device=dev),
+            slot_mapping=torch.full((max_bs,), -1, dtype=torch.int32, device=dev),
+            context_lens=torch.zeros(max_bs, dtype=torch.int32, device=dev),
+            block_tables=torch.zeros(max_bs, max_blocks, dtype=torch.int32, device=dev),
+            outputs=torch.zeros(max_bs, hf.hidden_size, dtype=hf.dtype, device=dev),
+            padded_bs=max_bs,
+        )
+        self.graph_bs = graph_batch_sizes(max_bs)
+        self.max_graph_bs = max_bs
+        self.graphs, self.graph_pool = {}, None
+        for bs in reversed(self.graph_bs):
+            self._set_decode_splits(bs)
+            set_context(False, slot_mapping=g["slot_mapping"][:bs], context_lens=g["context_lens"][:bs],
+                        block_tables=g["block_tables"][:bs])
+            g["outputs"][:bs] = self.model(g["input_ids"][:bs], g["positions"][:bs])  # warm-up: sizes the workspaces
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, self.graph_pool):
+                g["outputs"][:bs] = self.model(g["input_ids"][:bs], g["positions"][:bs])
+            if self.graph_pool is None:
+                self.graph_pool = graph.pool()
+            self.graphs[bs] = graph
+            torch.cuda.synchronize()
+            reset_context()
+        self.graph_vars = g
+
+    max_graph_bs = 0

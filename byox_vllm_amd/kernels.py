@@ -1,0 +1,196 @@
+"""Tensor-level wrappers over the C ABI (include/nv_hip.h).
+
+Each function checks shapes on the host (the kernels trust their arguments),
+passes raw device pointers plus the current HIP stream, and raises on error.
+Outputs are allocated with torch.empty unless an ``out`` buffer is given, so
+every call is capturable in a hipGraph (torch.cuda.graph) once warmed up.
+"""
+
+import torch
+
+from byox_vllm_amd import _C
+from byox_vllm_amd._C import check, dtype_code, lib, ptr, require_gpu, stream
+
+_workspaces: dict[tuple[int, str], torch.Tensor] = {}
+_retired: list[torch.Tensor] = []   # outgrown buffers stay alive: captured graphs may still point at them
+
+
+def workspace(nbytes: int, device, tag: str = "main") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag).  Size it before graph capture."""
+    key = (torch.device(device).index or 0, tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def rms_norm(x, weight, eps, out=None):
+    require_gpu(x, "rms_norm")
+    hidden = x.size(-1)
+    assert x.is_contiguous() and weight.numel() == hidden and weight.dtype == x.dtype
+    out = torch.empty_like(x) if out is None else out
+    rows = x.numel() // hidden
+    check(lib().nv_rmsnorm(ptr(x), ptr(weight), ptr(out), rows, hidden, hidden, hidden, eps,
+                           dtype_code(x.dtype), stream()), "nv_rmsnorm")
+    return out
+
+
+def add_rms_norm(x, residual, weight, eps, out=None, residual_out=None):
+    require_gpu(x, "add_rms_norm")
+    hidden = x.size(-1)
+    assert x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+    assert weight.numel() == hidden and weight.dtype == x.dtype == residual.dtype
+    out = torch.empty_like(x) if out is None else out
+    residual_out = torch.empty_like(x) if residual_out is None else residual_out
+    check(lib().nv_add_rmsnorm(ptr(x), ptr(residual), ptr(weight), ptr(out), ptr(residual_out),
+                               x.numel() // hidden, hidden, eps, dtype_code(x.dtype), stream()), "nv_add_rmsnorm")
+    return out, residual_out
+
+
+def rope_kv_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, slot_mapping=None,
+                  k_cache=None, v_cache=None, q_norm_w=None, k_norm_w=None, eps=1e-6):
+    """Rotate q and k inside ``qkv`` [T, (H+2Hkv)*D] in place; optionally store k/v into the paged cache."""
+    require_gpu(qkv, "rope_kv_store")
+    T = qkv.size(0)
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.size(1) >= (num_heads + 2 * num_kv_heads) * head_dim
+    assert positions.dtype == torch.int64 and positions.numel() == T and positions.is_contiguous()
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous() and cos_sin.size(-1) == head_dim
+    if k_cache is not None:
+        assert slot_mapping is not None and slot_mapping.dtype == torch.int32 and slot_mapping.numel() == T
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == qkv.dtype
+        assert k_cache.size(-1) == head_dim and k_cache.size(-2) == num_kv_heads
+    check(lib().nv_rope_kv_store(ptr(qkv), qkv.stride(0), ptr(positions), ptr(cos_sin), ptr(slot_mapping),
+                                 ptr(k_cache), ptr(v_cache), ptr(q_norm_w), ptr(k_norm_w), eps, T,
+                                 num_heads, num_kv_heads, head_dim, dtype_code(qkv.dtype), stream()),
+          "nv_rope_kv_store")
+    return qkv
+
+
+def kv_store(key, value, k_cache, v_cache, slot_mapping):
+    """store_kvcache: key/value [T, Hkv, D] (may be strided views of a qkv buffer)."""
+    require_gpu(key, "kv_store")
+    T, hkv, d = key.shape
+    row = hkv * d
+    assert key.stride(-1) == 1 and value.stride(-1) == 1 and key.stride(1) == d and value.stride(1) == d
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.size(-1) * k_cache.size(-2) == row
+    assert slot_mapping.dtype == torch.int32 and slot_mapping.numel() == T
+    check(lib().nv_kv_store(ptr(key), key.stride(0), ptr(value), value.stride(0), ptr(k_cache), ptr(v_cache),
+                            ptr(slot_mapping), T, row, dtype_code(key.dtype), stream()), "nv_kv_store")
+
+
+def pick_decode_splits(batch, num_kv_heads, max_context):
+    return lib().nv_paged_attn_decode_pick_splits(batch, num_kv_heads, max_context)
+
+
+def paged_attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale, out=None, num_splits=1):
+    """q [B, H, D] (row-strided ok); caches [NB, bs, Hkv, D]; returns [B, H, D]."""
+    require_gpu(q, "paged_attn_decode")
+    B, H, D = q.shape
+    nb, bs, hkv, d2 = k_cache.shape
+    assert d2 == D and q.stride(2) == 1 and q.stride(1) == D
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and v_cache.shape == k_cache.shape
+    assert context_lens.dtype == torch.int32 and context_lens.numel() == B and context_lens.is_contiguous()
+    assert block_tables.dtype == torch.int32 and block_tables.dim() == 2 and block_tables.size(0) >= B
+    assert block_tables.stride(1) == 1
+    out = torch.empty(B, H, D, dtype=q.dtype, device=q.device) if out is None else out
+    assert out.stride(2) == 1 and out.stride(1) == D
+    nbytes = lib().nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits)
+    ws = workspace(nbytes, q.device, "attn") if nbytes else None
+    check(lib().nv_paged_attn_decode(ptr(q), q.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                     block_tables.stride(0), ptr(context_lens), ptr(out), out.stride(0),
+                                     ptr(ws), ws.numel() if ws is not None else 0, B, H, hkv, D, bs, scale,
+                                     num_splits, dtype_code(q.dtype), stream()), "nv_paged_attn_decode")
+    return out
+
+
+def attn_prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scale, block_tables=None, out=None):
+    """Causal varlen attention.  Packed k/v [Tk, Hkv, D] or, with block_tables, paged caches [NB, bs, Hkv, D]."""
+    require_gpu(q, "attn_prefill")
+    Tq, H, D = q.shape
+    assert q.stride(2) == 1 and q.stride(1) == D
+    assert cu_seqlens_q.dtype == torch.int32 and cu_seqlens_k.dtype == torch.int32
+    n = cu_seqlens_q.numel() - 1
+    if block_tables is None:
+        hkv = k.size(1)
+        assert k.stride(2) == 1 and k.stride(1) == D and v.stride(1) == D and k.stride(0) == v.stride(0)
+        kv_stride, bs, bt_stride = k.stride(0), 0, 0
+    else:
+        assert k.is_contiguous() and v.is_contiguous() and k.dim() == 4
+        hkv, bs = k.size(2), k.size(1)
+        assert block_tables.dtype == torch.int32 and block_tables.size(0) >= n and block_tables.stride(1) == 1
+        kv_stride, bt_stride = hkv * D, block_tables.stride(0)
+    out = torch.empty(Tq, H, D, dtype=q.dtype, device=q.device) if out is None else out
+    check(lib().nv_attn_prefill(ptr(q), q.stride(0), ptr(k), ptr(v), kv_stride, ptr(cu_seqlens_q), ptr(cu_seqlens_k),
+                                ptr(block_tables), bt_stride, ptr(out), out.stride(0), n, max_seqlen_q, H, hkv, D, bs,
+                                scale, dtype_code(q.dtype), stream()), "nv_attn_prefill")
+    return out
+
+
+def silu_mul(x, out=None):
+    require_gpu(x, "silu_mul")
+    assert x.is_contiguous() and x.dim() == 2 and x.size(1) % 2 == 0
+    T, two_i = x.shape
+    out = torch.empty(T, two_i // 2, dtype=x.dtype, device=x.device) if out is None else out
+    check(lib().nv_silu_mul(ptr(x), ptr(out), T, two_i // 2, dtype_code(x.dtype), stream()), "nv_silu_mul")
+    return out
+
+
+def pick_split_k(M, N, K, target_blocks=256):
+    tiles = (N // 64) * ((M + 127) // 128)
+    return max(1, min(K // 128, target_blocks // max(tiles, 1)))
+
+
+def gemm(x, w, bias=None, out=None, split_k=None):
+    """x [M, K] @ w^T where ``w`` is a layers.quant.LinearWeight (dense, int8 or int4)."""
+    require_gpu(x, "gemm")
+    M, K = x.shape
+    assert K == w.in_features and x.stride(1) == 1 and x.dtype == w.dtype
+    N = w.out_features
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    assert out.stride(1) == 1 and out.size(1) == N
+    if bias is not None:
+        assert bias.numel() == N and bias.dtype == x.dtype
+    if split_k is None:
+        split_k = pick_split_k(M, N, K)
+    nbytes = lib().nv_gemm_workspace_bytes(M, N, split_k)
+    ws = workspace(nbytes, x.device, "gemm") if nbytes else None
+    check(lib().nv_gemm(ptr(x), x.stride(0), ptr(w.data), ptr(w.scales), ptr(bias), ptr(out), out.stride(0),
+                        M, N, K, w.fmt, split_k, ptr(ws), ws.numel() if ws is not None else 0, 0,
+                        dtype_code(x.dtype), stream()), "nv_gemm")
+    return out
+
+
+def embed(ids, weight, vocab_start=0, out=None):
+    require_gpu(weight, "embed")
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and weight.is_contiguous()
+    T, hidden = ids.numel(), weight.size(1)
+    out = torch.empty(T, hidden, dtype=weight.dtype, device=weight.device) if out is None else out
+    check(lib().nv_embed(ptr(ids), ptr(weight), ptr(out), T, hidden, vocab_start, weight.size(0),
+                         dtype_code(weight.dtype), stream()), "nv_embed")
+    return out
+
+
+def sample(logits, temperatures, noise=None, seed=0, out=None):
+    require_gpu(logits, "sample")
+    B, V = logits.shape
+    assert logits.stride(1) == 1 and temperatures.dtype == torch.float32 and temperatures.numel() == B
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.shape == logits.shape and noise.is_contiguous()
+    out = torch.empty(B, dtype=torch.int64, device=logits.device) if out is None else out
+    check(lib().nv_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(noise), ptr(out), B, V,
+                          seed & 0xFFFFFFFFFFFFFFFF, dtype_code(logits.dtype), stream()), "nv_sample")
+    return out
+
+
+def stage_decode_inputs(ids, positions, slots, context_lens, block_tables, g):
+    """Copy one step's metadata into the static buffers ``g`` of a captured graph (padding the tail)."""
+    bs, padded = ids.numel(), g["padded_bs"]
+    cols = block_tables.size(1)
+    assert block_tables.is_contiguous() and cols <= g["block_tables"].size(1)
+    check(lib().nv_stage_decode_inputs(ptr(ids), ptr(positions), ptr(slots), ptr(context_lens), ptr(block_tables),
+                                       cols, ptr(g["input_ids"]), ptr(g["positions"]), ptr(g["slot_mapping"]),
+                                       ptr(g["context_lens"]), ptr(g["block_tables"]), g["block_tables"].size(1),
+                                       bs, padded, stream()), "nv_stage_decode_inputs")

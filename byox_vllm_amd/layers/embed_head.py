@@ -1,0 +1,52 @@
+"""Vocab-parallel embedding and LM head (interface of nanovllm/layers/embed_head.py:9-66)."""
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from byox_vllm_amd import kernels
+from byox_vllm_amd.layers.linear import _tp
+from byox_vllm_amd.layers.quant import LinearWeight
+from byox_vllm_amd.utils.context import get_context
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank, self.tp_size = _tp()
+        assert num_embeddings % self.tp_size == 0
+        self.num_embeddings = num_embeddings
+        self.num_embeddings_per_partition = num_embeddings // self.tp_size
+        self.vocab_start_idx = self.num_embeddings_per_partition * self.tp_rank
+        self.vocab_end_idx = self.vocab_start_idx + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim), requires_grad=False)
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        shard = param.data.size(0)
+        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+
+    def forward(self, x: torch.Tensor):
+        # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
+        y = kernels.embed(x, self.weight.data, self.vocab_start_idx)
+        if self.tp_size > 1:
+            dist.all_reduce(y)
+        return y
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
+        assert not bias
+        super().__init__(num_embeddings, embedding_dim)
+
+    def forward(self, x: torch.Tensor):
+        context = get_context()
+        if context.is_prefill:
+            last = (context.cu_seqlens_q[1:] - 1).long()
+            x = x[last].contiguous()
+        logits = kernels.gemm(x, LinearWeight.dense(self.weight.data))
+        if self.tp_size > 1:
+            gathered = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            dist.gather(logits, gathered, 0)
+            logits = torch.cat(gathered, -1) if self.tp_rank == 0 else None
+        return logits

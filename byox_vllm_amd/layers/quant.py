@@ -1,0 +1,101 @@
+"""Weight containers for nv_gemm: dense, or weight-only int8 / int4 (group 128).
+
+The reference has no quantised linears (nanovllm/layers/linear.py is dense
+F.linear); the format below is this build's own.  Quantisation is symmetric
+with one scale per (output row, 128 input columns), scales kept in the model
+dtype:  int4: u = clamp(round(w/s), -8, 7) + 8, s = max|w|/7;  int8:
+q = clamp(round(w/s), -127, 127), s = max|w|/127.
+
+Device layout ("tiled"): the GEMM kernel gives each wavefront a 16-row tile of
+W and walks K in blocks of 128.  For tile nt and block kb, lane (c = lane % 16,
+g = lane // 16) needs W[16 nt + c][128 kb + 32 ks + 8 g + e] for ks in 0..3,
+e in 0..7.  Those 32 values are stored contiguously per lane:
+  int4: 4 dwords (dword ks, nibble e)  -> tensor int32 [N/16, K/128, 64, 4]
+  int8: 32 bytes (byte 8 ks + e)       -> tensor int8  [N/16, K/128, 64, 32]
+so one or two 16-byte loads per lane fetch a whole K-block, fully coalesced.
+Scales are stored transposed, [K/128, N].
+"""
+
+import torch
+
+from byox_vllm_amd._C import W_DENSE, W_INT4, W_INT8
+
+GROUP = 128
+
+
+def _tile_index_view(t: torch.Tensor) -> torch.Tensor:
+    """[N, K] -> [N/16, K/128, g(4), c(16), ks(4), e(8)] in lane-major order."""
+    n, k = t.shape
+    return t.view(n // 16, 16, k // GROUP, 4, 4, 8).permute(0, 2, 4, 1, 3, 5)
+
+
+def _untile(t: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """Inverse of _tile_index_view: [N/16, K/128, 4, 16, 4, 8] -> [N, K]."""
+    return t.permute(0, 3, 1, 4, 2, 5).reshape(n, k)
+
+
+def _scales(w: torch.Tensor, qmax: int):
+    n, k = w.shape
+    assert k % GROUP == 0 and n % 16 == 0, f"weight [{n}, {k}] needs N % 16 == 0 and K % 128 == 0"
+    g = w.float().view(n, k // GROUP, GROUP)
+    s = (g.abs().amax(dim=-1) / qmax).clamp_min(1e-8).to(w.dtype)
+    return g, s
+
+
+class LinearWeight:
+    """What nv_gemm consumes: ``fmt``, ``data`` (device tensor), ``scales`` ([K/128, N] or None)."""
+
+    def __init__(self, fmt, data, scales, out_features, in_features, dtype):
+        self.fmt, self.data, self.scales = fmt, data, scales
+        self.out_features, self.in_features, self.dtype = out_features, in_features, dtype
+
+    @property
+    def nbytes(self) -> int:
+        n = self.data.numel() * self.data.element_size()
+        return n + (self.scales.numel() * self.scales.element_size() if self.scales is not None else 0)
+
+    @classmethod
+    def dense(cls, w: torch.Tensor):
+        assert w.dim() == 2 and w.is_contiguous()
+        return cls(W_DENSE, w, None, w.size(0), w.size(1), w.dtype)
+
+    @classmethod
+    def int4(cls, w: torch.Tensor):
+        n, k = w.shape
+        g, s = _scales(w, 7)
+        u = (torch.clamp(torch.round(g / s.float().unsqueeze(-1)), -8, 7) + 8).to(torch.int32).view(n, k)
+        shifts = torch.arange(0, 32, 4, device=w.device, dtype=torch.int32)
+        tiled = (_tile_index_view(u) << shifts).sum(dim=-1, dtype=torch.int64)
+        tiled = (tiled & 0xFFFFFFFF).to(torch.int64)
+        tiled = torch.where(tiled >= 2 ** 31, tiled - 2 ** 32, tiled).to(torch.int32)
+        return cls(W_INT4, tiled.reshape(n // 16, k // GROUP, 64, 4).contiguous(), s.t().contiguous(), n, k, w.dtype)
+
+    @classmethod
+    def int8(cls, w: torch.Tensor):
+        n, k = w.shape
+        g, s = _scales(w, 127)
+        q = torch.clamp(torch.round(g / s.float().unsqueeze(-1)), -127, 127).to(torch.int8).view(n, k)
+        tiled = _tile_index_view(q).reshape(n // 16, k // GROUP, 64, 32).contiguous()
+        return cls(W_INT8, tiled, s.t().contiguous(), n, k, w.dtype)
+
+    @classmethod
+    def make(cls, w: torch.Tensor, quantization: str | None):
+        if quantization is None:
+            return cls.dense(w.contiguous())
+        return cls.int4(w) if quantization == "w4a16" else cls.int8(w)
+
+    # -- logical (untiled) views, used by tests to compare with the CPU oracle's format ----
+    def logical_int4(self):
+        """-> (uint8 [N, K/2] two values per byte, low nibble = even index; scales [N, K/128])."""
+        assert self.fmt == W_INT4
+        n, k = self.out_features, self.in_features
+        d = self.data.view(n // 16, k // GROUP, 4, 16, 4, 1).to(torch.int64) & 0xFFFFFFFF
+        shifts = torch.arange(0, 32, 4, device=d.device, dtype=torch.int64)
+        u = _untile((d >> shifts) & 0xF, n, k).to(torch.uint8)
+        return (u[:, 0::2] | (u[:, 1::2] << 4)).contiguous(), self.scales.t().contiguous()
+
+    def logical_int8(self):
+        assert self.fmt == W_INT8
+        n, k = self.out_features, self.in_features
+        q = _untile(self.data.view(n // 16, k // GROUP, 4, 16, 4, 8), n, k)
+        return q.contiguous(), self.scales.t().contiguous()

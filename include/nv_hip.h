@@ -1,0 +1,153 @@
+/*
+ * nv_hip.h — C ABI of the MI355X (gfx950) kernels behind nanovllm's paged-KV
+ * decode hot path.
+ *
+ * The reference engine has no FFI of its own: its hot path is Python calling
+ * third-party kernels (flash-attn, Triton, inductor, cuBLAS).  Each entry point
+ * below replaces one such call site; the comment above it names the reference
+ * file:line.  The Python layers in byox_vllm_amd/layers bind these with ctypes.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory and integer sizes, no framework types;
+ *   - `dtype` is NV_BF16 or NV_F16 (the model dtype of activations/KV cache);
+ *   - strides are in ELEMENTS of the tensor's dtype unless the name says bytes;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return 0 on success, a negative NV_ERR_* otherwise (text via nv_last_error);
+ *     nothing throws across the boundary;
+ *   - no entry point allocates, synchronises or reads device memory on the host,
+ *     so every call can be captured into a hipGraph; scratch space is passed in
+ *     by the caller (`workspace`), sized by the matching *_workspace_bytes().
+ */
+#ifndef NV_HIP_H
+#define NV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NV_OK 0
+#define NV_ERR_INVALID (-1)     /* bad argument (shape, alignment, dtype) */
+#define NV_ERR_LAUNCH (-2)      /* the HIP runtime refused the launch */
+#define NV_ERR_UNSUPPORTED (-3) /* valid request outside what the kernels cover */
+
+#define NV_BF16 0
+#define NV_F16 1
+
+/* weight formats of nv_gemm */
+#define NV_W_DENSE 0 /* [N, K] row-major in the model dtype (reference layout, linear.py:24) */
+#define NV_W_INT8 1  /* tiled int8, group-128 scales, see byox_vllm_amd/layers/quant.py */
+#define NV_W_INT4 2  /* tiled int4, group-128 scales, see byox_vllm_amd/layers/quant.py */
+
+typedef void* nv_stream_t;
+
+int nv_version(void);
+const char* nv_last_error(void);
+
+/* RMSNorm.rms_forward — nanovllm/layers/layernorm.py:16-26.
+ * out[r] = to_dtype(x[r] * rsqrt(mean(x[r]^2) + eps)) * weight, fp32 inside.
+ * rows of `hidden` contiguous elements; hidden % 8 == 0. */
+int nv_rmsnorm(const void* x, const void* weight, void* out, int64_t rows, int hidden,
+               int64_t x_row_stride, int64_t out_row_stride, float eps, int dtype, nv_stream_t stream);
+
+/* RMSNorm.add_rms_forward — nanovllm/layers/layernorm.py:28-40.
+ * s = fp32(x) + fp32(residual); residual_out = to_dtype(s); out = norm of the
+ * UNROUNDED s, scaled by weight.  out may alias x, residual_out may alias residual. */
+int nv_add_rmsnorm(const void* x, const void* residual, const void* weight, void* out, void* residual_out,
+                   int64_t rows, int hidden, float eps, int dtype, nv_stream_t stream);
+
+/* RotaryEmbedding.forward + store_kvcache (+ Qwen3 q_norm/k_norm) fused —
+ * nanovllm/layers/rotary_embedding.py:37-48, layers/attention.py:10-49,
+ * models/qwen3.py:76-83.
+ * qkv: [T, (H + 2*Hkv) * D] rows with stride qkv_row_stride; q and k are rotated
+ * IN PLACE (NeoX halves, fp32, table cos_sin = fp32 [max_pos, D] = cat(cos, sin)).
+ * If q_norm_w/k_norm_w are non-NULL each head is RMS-normalised first.
+ * If k_cache/v_cache are non-NULL, token t's rotated k and its v are copied to
+ * cache row slot_mapping[t] (caches are [num_slots, Hkv*D]); slots < 0 are skipped. */
+int nv_rope_kv_store(void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                     const int32_t* slot_mapping, void* k_cache, void* v_cache,
+                     const void* q_norm_w, const void* k_norm_w, float eps,
+                     int64_t T, int H, int Hkv, int D, int dtype, nv_stream_t stream);
+
+/* store_kvcache — nanovllm/layers/attention.py:10-49 (stand-alone form).
+ * Copies key[t] / value[t] (row_elems = Hkv*D contiguous elements, row strides
+ * given) to cache row slot_mapping[t]; slots < 0 are skipped. */
+int nv_kv_store(const void* key, int64_t key_row_stride, const void* value, int64_t value_row_stride,
+                void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                int64_t T, int row_elems, int dtype, nv_stream_t stream);
+
+/* flash_attn_with_kvcache as called at nanovllm/layers/attention.py:88-96:
+ * one query token per sequence against a paged cache.
+ * q [B, H, D] (row stride q_row_stride), k_cache/v_cache [num_blocks, block_size, Hkv, D],
+ * block_tables int32 [B, bt_stride] (pad -1), context_lens int32 [B] (0 => zero output),
+ * out [B, H, D] (row stride out_row_stride).  D in {64, 128}; H/Hkv <= 16.
+ * num_splits >= 1 partitions each sequence's keys over that many workgroups
+ * (flash-decoding); 0 lets the library choose.  workspace must hold
+ * nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits) bytes. */
+size_t nv_paged_attn_decode_workspace_bytes(int B, int H, int D, int num_splits);
+int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context);
+int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                         const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
+                         void* out, int64_t out_row_stride, void* workspace, size_t workspace_bytes,
+                         int B, int H, int Hkv, int D, int block_size, float scale, int num_splits,
+                         int dtype, nv_stream_t stream);
+
+/* flash_attn_varlen_func as called at nanovllm/layers/attention.py:75-86:
+ * causal (bottom-right aligned) variable-length prefill.
+ * q [Tq, H, D]; without block_tables k/v are packed [Tk, Hkv, D] (row strides
+ * given); with block_tables k/v are the paged caches and sequence i reads its
+ * cu_seqlens_k[i+1]-cu_seqlens_k[i] keys through block_tables[i]. */
+int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* k, const void* v, int64_t kv_row_stride,
+                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                    const int32_t* block_tables, int bt_stride, void* out, int64_t out_row_stride,
+                    int num_seqs, int max_seqlen_q, int H, int Hkv, int D, int block_size, float scale,
+                    int dtype, nv_stream_t stream);
+
+/* SiluAndMul.forward — nanovllm/layers/activation.py:10-13.
+ * out[t, i] = to_dtype(silu(x[t, i])) * x[t, I + i], x [T, 2I]. */
+int nv_silu_mul(const void* x, void* out, int64_t T, int I, int dtype, nv_stream_t stream);
+
+/* F.linear at nanovllm/layers/linear.py:49,70,144 and embed_head.py:59:
+ * out[M, N] = x[M, K] . W[N, K]^T (+ bias[N]), fp32 accumulation, output in dtype.
+ * wfmt selects dense or weight-only int8/int4 (dequantised in registers; the
+ * reference has no quantised path, its dense F.linear on the dequantised weight
+ * is the oracle).  scales: [K/128, N] in the model dtype for int8/int4, else NULL.
+ * K % 128 == 0, N % 64 == 0 for int8/int4; K % 32 == 0, N % 16 == 0 for dense.
+ * split_k > 1 spreads K over that many workgroups; workspace must then hold
+ * nv_gemm_workspace_bytes(M, N, split_k) bytes.
+ * flags: NV_GEMM_SILU_MUL — W rows are gate/up interleaved in 16-row groups and
+ * the epilogue writes silu(gate)*up, out is [M, N/2]. */
+#define NV_GEMM_SILU_MUL 1
+size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k);
+int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
+            void* out, int64_t out_row_stride, int64_t M, int N, int K, int wfmt, int split_k,
+            void* workspace, size_t workspace_bytes, int flags, int dtype, nv_stream_t stream);
+
+/* VocabParallelEmbedding.forward (gather + mask) — nanovllm/layers/embed_head.py:33-41.
+ * out[t] = weight[ids[t] - vocab_start] if vocab_start <= ids[t] < vocab_start + vocab_local else 0. */
+int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int hidden,
+             int64_t vocab_start, int64_t vocab_local, int dtype, nv_stream_t stream);
+
+/* Sampler.forward — nanovllm/layers/sampler.py:11-15.
+ * token[b] = argmax_v softmax(logits[b]/T[b])_v / max(noise[b, v], 1e-10); noise is
+ * Exp(1): read from `noise` (fp32 [B, V]) when given, else drawn in-kernel from
+ * (seed, b, v).  T[b] == 0 takes argmax(logits[b]) (greedy extension).  Ties
+ * resolve to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V. */
+int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
+              int64_t* tokens, int B, int V, uint64_t seed, int dtype, nv_stream_t stream);
+
+/* Graph-replay staging — nanovllm/engine/model_runner.py:246-252 as ONE launch:
+ * copies the step's ids/positions/slots/context_lens/block_tables into the
+ * static buffers a captured decode step reads, padding rows [bs, padded_bs)
+ * with slot -1 / context_len 0. */
+int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positions, const int32_t* slots,
+                           const int32_t* context_lens, const int32_t* block_tables, int bt_cols,
+                           int64_t* g_ids, int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
+                           int32_t* g_block_tables, int g_bt_cols, int bs, int padded_bs, nv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NV_HIP_H */

@@ -48,6 +48,16 @@ def random_weights(cfg, seed=0, dtype=None):
     return w
 
 
+def tiny_config(style, dtype):
+    """Small Qwen2-style (QKV bias, D=64, GQA 2) / Qwen3-style (head norms, D=128) shapes for fixtures."""
+    qwen3 = style == "qwen3"
+    return SimpleNamespace(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2 if qwen3 else 4, num_key_value_heads=1 if qwen3 else 2,
+                           head_dim=128 if qwen3 else 64, max_position_embeddings=128, rms_norm_eps=1e-6,
+                           hidden_act="silu", attention_bias=not qwen3, rope_theta=1000000.0, rope_scaling=None,
+                           tie_word_embeddings=not qwen3, dtype=dtype)
+
+
 QUANT_SUFFIXES = ("qkv_proj.weight", "o_proj.weight", "gate_up_proj.weight", "down_proj.weight")
 
 

@@ -148,12 +148,7 @@ def gen_sharding():
     np.savez_compressed(os.path.join(HERE, "sharding.npz"), **out)
 
 
-def tiny_cfg(style, dtype):
-    return SimpleNamespace(vocab_size=256, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-                           num_attention_heads=4, num_key_value_heads=2, head_dim=32 if style == "qwen3" else 16,
-                           max_position_embeddings=128, rms_norm_eps=1e-6, hidden_act="silu",
-                           attention_bias=(style == "qwen2"), rope_theta=1000000.0, rope_scaling=None,
-                           tie_word_embeddings=(style == "qwen2"), dtype=dtype)
+tiny_cfg = OM.tiny_config
 
 
 def gen_model():

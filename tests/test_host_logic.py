@@ -1,0 +1,252 @@
+"""Integer/host side of the hot path against the reference's own known-answer tests.
+
+The expected values are the ones asserted in the reference's tests
+(tests/test_prepare_funcs.py, tests/test_cache.py, tests/test_scheduler.py),
+re-stated against this package's classes.
+"""
+
+from collections import deque
+from types import SimpleNamespace
+from unittest.mock import Mock
+
+import torch
+
+from byox_vllm_amd.engine.block_manager import BlockManager
+from byox_vllm_amd.engine.model_runner import ModelRunner, graph_batch_sizes
+from byox_vllm_amd.engine.scheduler import Scheduler
+from byox_vllm_amd.engine.sequence import Sequence, SequenceStatus
+from byox_vllm_amd.utils.context import get_context, reset_context
+
+
+def make_runner():
+    runner = ModelRunner.__new__(ModelRunner)   # as the reference's tests do: no __init__, only block_size
+    runner.block_size = 16
+    runner.device = torch.device("cpu")
+    runner._prepare_block_tables = Mock(return_value=torch.tensor([[0, -1, -1, -1]]))
+    return runner
+
+
+def eq(t, values):
+    return t is not None and t.cpu().tolist() == values
+
+
+def test_prepare_prefill_single_and_multiple():
+    runner = make_runner()
+    seq = Sequence([1, 2, 3, 4, 5], block_size=16)
+    seq.block_table = [0]
+    ids, pos = runner._prepare_prefill([seq])
+    c = get_context()
+    assert c.is_prefill and eq(c.cu_seqlens_q, [0, 5]) and eq(c.cu_seqlens_k, [0, 5])
+    assert (c.max_seqlen_q, c.max_seqlen_k) == (5, 5) and eq(c.slot_mapping, [0, 1, 2, 3, 4])
+    assert c.context_lens is None and c.block_tables is None
+    assert eq(ids, [1, 2, 3, 4, 5]) and eq(pos, [0, 1, 2, 3, 4])
+    assert ids.dtype == torch.int64 and c.slot_mapping.dtype == torch.int32 and c.cu_seqlens_q.dtype == torch.int32
+    reset_context()
+    s0, s1 = Sequence([1, 2, 3], 16), Sequence([4, 5, 6, 7, 8], 16)
+    s0.block_table, s1.block_table = [0], [1]
+    ids, pos = runner._prepare_prefill([s0, s1])
+    c = get_context()
+    assert eq(c.cu_seqlens_q, [0, 3, 8]) and eq(c.cu_seqlens_k, [0, 3, 8]) and c.max_seqlen_q == 5
+    assert eq(c.slot_mapping, [0, 1, 2, 16, 17, 18, 19, 20]) and c.block_tables is None
+    assert eq(ids, [1, 2, 3, 4, 5, 6, 7, 8]) and eq(pos, [0, 1, 2, 0, 1, 2, 3, 4])
+    reset_context()
+
+
+def test_prepare_prefill_with_cached_tokens():
+    runner = make_runner()
+    seq = Sequence([1, 2, 3, 4, 5, 6], 16)
+    seq.num_cached_tokens, seq.block_table = 3, [0, 1]
+    ids, pos = runner._prepare_prefill([seq])
+    c = get_context()
+    assert eq(c.cu_seqlens_q, [0, 3]) and eq(c.cu_seqlens_k, [0, 6]) and (c.max_seqlen_q, c.max_seqlen_k) == (3, 6)
+    assert eq(c.slot_mapping, [0, 1, 2, 3, 4, 5]) and eq(c.block_tables, [[0, -1, -1, -1]])
+    assert eq(ids, [4, 5, 6]) and eq(pos, [3, 4, 5])
+    reset_context()
+    s0, s1 = Sequence([1, 2, 3, 4, 5], 16), Sequence([6, 7, 8, 9, 10, 11], 16)
+    s0.num_cached_tokens, s1.num_cached_tokens = 2, 1
+    s0.block_table, s1.block_table = [0], [1]
+    ids, pos = runner._prepare_prefill([s0, s1])
+    c = get_context()
+    assert eq(c.cu_seqlens_q, [0, 3, 8]) and eq(c.cu_seqlens_k, [0, 5, 11]) and (c.max_seqlen_q, c.max_seqlen_k) == (5, 6)
+    assert eq(c.slot_mapping, [0, 1, 2, 3, 4, 16, 17, 18, 19, 20, 21])
+    assert eq(ids, [3, 4, 5, 7, 8, 9, 10, 11]) and eq(pos, [2, 3, 4, 1, 2, 3, 4, 5])
+    reset_context()
+
+
+def test_prepare_decode_cases():
+    runner = make_runner()
+    seq = Sequence([1, 2, 3, 4, 5], 16)
+    seq.status, seq.block_table = SequenceStatus.RUNNING, [0, -1, -1, -1]
+    runner._prepare_block_tables = Mock(return_value=torch.tensor([[0, -1, -1, -1]], dtype=torch.int32))
+    ids, pos = runner._prepare_decode([seq])
+    c = get_context()
+    assert not c.is_prefill and c.cu_seqlens_q is None and c.cu_seqlens_k is None and c.max_seqlen_q == 0
+    assert eq(c.slot_mapping, [-12]) and eq(c.context_lens, [5]) and eq(c.block_tables, [[0, -1, -1, -1]])
+    assert eq(ids, [5]) and eq(pos, [4])
+    reset_context()
+    s0, s1 = Sequence([1, 2, 3], 16), Sequence([4, 5, 6, 7], 16)
+    s0.block_table, s1.block_table = [0, -1, -1, -1], [1, -1, -1, -1]
+    ids, pos = runner._prepare_decode([s0, s1])
+    c = get_context()
+    assert eq(c.slot_mapping, [-14, -13]) and eq(c.context_lens, [3, 4]) and eq(ids, [3, 7]) and eq(pos, [2, 3])
+    reset_context()
+    s0, s1 = Sequence([1, 2, 3, 4], 16), Sequence([5, 6, 7, 8, 9], 16)
+    s0.block_table, s1.block_table = [0, -1, -1, -1], [1, -1, -1, -1]
+    s0.num_cached_tokens, s1.num_cached_tokens = 2, 3
+    ids, pos = runner._prepare_decode([s0, s1])
+    c = get_context()
+    assert eq(c.slot_mapping, [-13, -12]) and eq(c.context_lens, [4, 5]) and eq(ids, [4, 9]) and eq(pos, [3, 4])
+    reset_context()
+
+
+def test_prepare_block_tables_pads_with_minus_one():
+    runner = ModelRunner.__new__(ModelRunner)
+    runner.block_size, runner.device = 16, torch.device("cpu")
+    s0, s1 = Sequence([1] * 40, 16), Sequence([2] * 5, 16)
+    s0.block_table, s1.block_table = [4, 9, 2], [7]
+    bt = runner._prepare_block_tables([s0, s1])
+    assert bt.dtype == torch.int32 and bt.tolist() == [[4, 9, 2], [7, -1, -1]]
+    # real decode slots: last block id * block_size + tokens in last block - 1 (model_runner.py:215)
+    runner._prepare_decode([s0, s1])
+    assert get_context().slot_mapping.tolist() == [2 * 16 + 7, 7 * 16 + 4]
+    reset_context()
+
+
+def test_block_manager_prefix_cache_trace():
+    m = BlockManager(10, 16)
+    common = [i for i in range(3) for _ in range(16)]
+    seq0 = Sequence(common + [3] * 4, 16)
+    m.allocate(seq0)
+    assert seq0.block_table == [0, 1, 2, 3] and seq0.num_cached_tokens == 0
+    assert m.used_block_ids == {0, 1, 2, 3} and m.free_block_ids == deque([4, 5, 6, 7, 8, 9])
+    parent = -1
+    for b in (0, 1, 2):
+        parent = m._compute_hash(tuple(common[b * 16:(b + 1) * 16]), parent)
+        assert m.blocks[b].hash == parent and m.blocks[b].ref_count == 1
+    assert m.blocks[3].hash == -1
+    seq1 = Sequence(common + [3] * 5, 16)
+    m.allocate(seq1)                                  # hit on blocks still in use
+    assert seq1.block_table == [0, 1, 2, 4] and seq1.num_cached_tokens == 48 and seq1.num_cached_blocks == 3
+    assert [m.blocks[b].ref_count for b in (0, 1, 2)] == [2, 2, 2] and m.free_block_ids == deque([5, 6, 7, 8, 9])
+    m.deallocate(seq0)
+    assert m.free_block_ids == deque([5, 6, 7, 8, 9, 3])
+    m.deallocate(seq1)
+    assert m.free_block_ids == deque([5, 6, 7, 8, 9, 3, 4, 2, 1, 0])
+    seq2 = Sequence(common + [3] * 6, 16)
+    m.allocate(seq2)                                  # hit on freed blocks: revived
+    assert seq2.block_table == [0, 1, 2, 5] and seq2.num_cached_tokens == 48
+    assert m.used_block_ids == {0, 1, 2, 5} and m.free_block_ids == deque([6, 7, 8, 9, 3, 4])
+    m.deallocate(seq2)
+    assert m.free_block_ids == deque([6, 7, 8, 9, 3, 4, 5, 2, 1, 0])
+    seq3 = Sequence([99] * 160, 16)
+    m.allocate(seq3)                                  # miss everywhere: eviction in free-list order
+    assert seq3.block_table == [6, 7, 8, 9, 3, 4, 5, 2, 1, 0] and m.free_block_ids == deque([])
+    m.deallocate(seq3)
+    assert m.free_block_ids == deque([0, 1, 2, 5, 4, 3, 9, 8, 7, 6])
+
+
+def test_block_manager_stale_hash_mapping_and_append():
+    m = BlockManager(10, 16)
+    seq0 = Sequence([i for i in range(8) for _ in range(16)], 16)
+    m.allocate(seq0)
+    m.deallocate(seq0)
+    assert len(m.hash_to_block_id) == 8
+    seq1 = Sequence([i for i in range(8, 16) for _ in range(16)], 16)
+    m.allocate(seq1)
+    assert len(m.hash_to_block_id) == 16
+    # decode appends: token 129 opens a block, token 144 seals it with a chained hash
+    seq1.append_token(5)
+    assert m.can_append(seq1)
+    m.may_append(seq1)
+    assert len(seq1.block_table) == 9
+    for _ in range(15):
+        seq1.append_token(5)
+        m.may_append(seq1)
+    last = m.blocks[seq1.block_table[-1]]
+    assert last.hash == m._compute_hash([5] * 16, m.blocks[seq1.block_table[-2]].hash)
+
+
+def _sched(num_blocks=10, block_size=256, **kw):
+    cfg = dict(max_num_seqs=512, max_num_batched_tokens=16384, eos=-1, num_kvcache_blocks=num_blocks,
+               kvcache_block_size=block_size)
+    cfg.update(kw)
+    return Scheduler(SimpleNamespace(**cfg))
+
+
+def test_scheduler_waits_for_blocks():
+    s = _sched()
+    seq0 = Sequence([i for i in range(3) for _ in range(256)] + [3] * 4, 256)
+    s.add(seq0)
+    assert s.schedule() == ([seq0], True)
+    seq1 = Sequence([i for i in range(7) for _ in range(256)], 256)
+    s.add(seq1)
+    assert s.schedule() == ([seq0], False)            # seq1 cannot be allocated: seq0 keeps decoding
+
+
+def test_scheduler_rotates_on_token_budget():
+    s = _sched(max_num_batched_tokens=1000)
+    seq0 = Sequence([i for i in range(7) for _ in range(256)], 256)
+    s.add(seq0)
+    assert s.schedule() == ([], False)
+    seq1 = Sequence([i for i in range(3) for _ in range(256)], 256)
+    seq2 = Sequence([3] * 256, 256)
+    s.add(seq1)
+    s.add(seq2)
+    assert s.waiting == deque([seq0, seq1, seq2])
+    assert s.schedule() == ([], False)
+    assert s.waiting == deque([seq1, seq2, seq0])
+    seqs, is_prefill = s.schedule()
+    seq1.append_token(100)
+    assert seqs == [seq1] and is_prefill and s.waiting == deque([seq0, seq2])
+    assert s.schedule() == ([seq1], False)
+    assert s.waiting == deque([seq2, seq0])
+
+
+def test_scheduler_preempts_itself_when_pool_is_empty():
+    s = _sched()
+    seq0 = Sequence([i for i in range(7) for _ in range(256)], 256)
+    s.add(seq0)
+    s.schedule()
+    seq0.append_token(100)
+    assert s.running == deque([seq0]) and s.block_manager.free_block_ids == deque([7, 8, 9])
+    seq1 = Sequence([i for i in range(7, 9) for _ in range(256)], 256)
+    s.add(seq1)
+    s.schedule()
+    seq1.append_token(101)
+    assert s.running == deque([seq0, seq1]) and s.block_manager.free_block_ids == deque([9])
+    s.schedule()
+    assert s.running == deque([seq0]) and s.waiting == deque([seq1])
+    assert s.block_manager.free_block_ids == deque([8, 7])
+    assert seq0.block_table == [0, 1, 2, 3, 4, 5, 6, 9] and seq1.block_table == []
+
+
+def test_scheduler_postprocess_eos_and_max_tokens():
+    from byox_vllm_amd.sampling_params import SamplingParams
+    s = _sched(block_size=16, eos=7)
+    a = Sequence([1, 2, 3], 16, SamplingParams(max_tokens=2))
+    b = Sequence([4, 5], 16, SamplingParams(max_tokens=8, ignore_eos=True))
+    s.add(a)
+    s.add(b)
+    seqs, _ = s.schedule()
+    s.postprocess(seqs, [7, 7])                       # a stops on eos, b ignores it
+    assert a.is_finished and not b.is_finished and a.block_table == [] and s.running == deque([b])
+
+
+def test_graph_batch_sizes_follow_reference():
+    assert graph_batch_sizes(512)[:6] == [1, 2, 4, 8, 16, 32] and graph_batch_sizes(512)[-1] == 512
+    assert graph_batch_sizes(8) == [1, 2, 4, 8]
+
+
+def test_sampling_params_and_config_extensions():
+    import pytest
+    from byox_vllm_amd import SamplingParams
+    from byox_vllm_amd.config import Config, qwen2_config
+    assert SamplingParams().temperature == 1.0 and SamplingParams(temperature=0.0).temperature == 0.0
+    with pytest.raises(AssertionError):
+        SamplingParams(temperature=-1.0)
+    cfg = Config("synthetic", hf_config=qwen2_config("qwen2-0.5b"), kvcache_block_size=16, max_model_len=999999, max_num_batched_tokens=32768)
+    assert cfg.max_model_len == 32768 and cfg.hf_config.head_dim == 64
+    with pytest.raises(AssertionError):
+        Config("/nonexistent-model-dir")
+    with pytest.raises(AssertionError):
+        Config("synthetic", hf_config=qwen2_config("qwen2-7b"), tensor_parallel_size=9)

@@ -1,0 +1,354 @@
+"""HIP kernels through the C ABI against the CPU oracle and the reference-generated goldens."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as OA
+from oracle import layers as L
+from oracle import quant as Q
+
+pytestmark = pytest.mark.gpu
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+EPS = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}   # one unit in the last place at magnitude 1
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def t(a, dt):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+def ulp_close(got, want, name, ulps=1.0):
+    """|got - want| <= ulps * eps * max(|want|, tiny) elementwise (fp values that differ by rounding only)."""
+    got, want = got.float().cpu(), want.float().cpu()
+    tol = ulps * EPS[name] * want.abs().clamp_min(1e-3) * 2
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} beyond {ulps} ulp; max abs {(got - want).abs().max()}"
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("h", [896, 128, 64])
+def test_rmsnorm_vs_reference_golden(golden, name, h):
+    from byox_vllm_amd import kernels
+    g, dt = golden.npz("layers"), DT[name]
+    k = f"rms_{name}_{h}_"
+    x, r, w = t(g[k + "x"], dt), t(g[k + "r"], dt), t(g[k + "w"], dt)
+    y = kernels.rms_norm(dev(x), dev(w), 1e-6)
+    ulp_close(y, t(g[k + "y"], dt), name)
+    y2, r2 = kernels.add_rms_norm(dev(x), dev(r), dev(w), 1e-6)
+    ulp_close(y2, t(g[k + "y2"], dt), name)
+    assert torch.equal(r2.cpu(), t(g[k + "r2"], dt)), "residual (a single fp32 add, then one rounding) must be bit-exact"
+    # the sum of squares is the only place where summation order can differ: count exact matches too
+    exact = (y.cpu() == t(g[k + "y"], dt)).float().mean().item()
+    assert exact > 0.98
+
+
+def test_rmsnorm_inplace_large_rows():
+    from byox_vllm_amd import kernels
+    torch.manual_seed(0)
+    x = torch.randn(130, 3584).to(torch.bfloat16)
+    r = torch.randn(130, 3584).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(3584)).to(torch.bfloat16)
+    want_y, want_r = L.add_rms_norm(x, r, w, 1e-6)
+    xd, rd = dev(x), dev(r)
+    kernels.add_rms_norm(xd, rd, dev(w), 1e-6, out=xd, residual_out=rd)
+    assert torch.equal(rd.cpu(), want_r)
+    ulp_close(xd, want_y, "bf16")
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("d", [64, 128])
+def test_rope_bit_exact_vs_reference_golden(golden, name, d):
+    from byox_vllm_amd.layers.rotary_embedding import RotaryEmbedding
+    g, dt = golden.npz("layers"), DT[name]
+    k = f"rope_{name}_{d}_"
+    rope = RotaryEmbedding(d, d, 512, 1000000.0)
+    assert torch.equal(rope.cos_sin_cache, torch.from_numpy(g[f"rope_table_{d}"]))
+    rope = rope.to("cuda")
+    q, kk = dev(t(g[k + "q"], dt)), dev(t(g[k + "k"], dt))
+    rope(dev(torch.from_numpy(g[k + "pos"])), q, kk)
+    assert torch.equal(q.cpu(), t(g[k + "q2"], dt))
+    assert torch.equal(kk.cpu(), t(g[k + "k2"], dt))
+
+
+@pytest.mark.parametrize("name", list(DT))
+def test_silu_mul_vs_reference_golden(golden, name):
+    from byox_vllm_amd import kernels
+    g, dt = golden.npz("layers"), DT[name]
+    y = kernels.silu_mul(dev(t(g[f"silu_{name}_x"], dt)))
+    ulp_close(y, t(g[f"silu_{name}_y"], dt), name)   # device expf vs libm expf: at most the last bit
+
+
+@pytest.mark.parametrize("qk_norm", [False, True])
+@pytest.mark.parametrize("d", [64, 128])
+def test_fused_rope_norm_kv_store(qk_norm, d):
+    """q/k head-norm + RoPE in place + paged store == oracle rms_norm -> rope_qk -> store_kvcache."""
+    from byox_vllm_amd import kernels
+    torch.manual_seed(1)
+    T, H, Hkv, bs, nb = 9, 4, 2, 16, 6
+    dt = torch.bfloat16
+    qkv = torch.randn(T, (H + 2 * Hkv) * d).to(dt)
+    pos = torch.randint(0, 200, (T,))
+    slots = torch.tensor([3, 17, 18, -1, 40, 95, 0, 64, 65], dtype=torch.int32)
+    table = L.build_cos_sin_cache(d, 256, 1e6)
+    qn = (1 + 0.1 * torch.randn(d)).to(dt)
+    kn = (1 + 0.1 * torch.randn(d)).to(dt)
+    q, k, v = qkv.split([H * d, Hkv * d, Hkv * d], dim=-1)
+    q, k, v = q.reshape(T, H, d), k.reshape(T, Hkv, d), v.reshape(T, Hkv, d)
+    if qk_norm:
+        q, k = L.rms_norm(q, qn, 1e-6), L.rms_norm(k, kn, 1e-6)
+    q2, k2 = L.rope_qk(pos, q, k, table)
+    kc, vc = torch.zeros(nb, bs, Hkv, d, dtype=dt), torch.zeros(nb, bs, Hkv, d, dtype=dt)
+    OA.store_kvcache(k2, v, kc, vc, slots)
+
+    qkv_d, kc_d, vc_d = dev(qkv), dev(torch.zeros_like(kc)), dev(torch.zeros_like(vc))
+    kernels.rope_kv_store(qkv_d, dev(pos), dev(table), H, Hkv, d, slot_mapping=dev(slots), k_cache=kc_d, v_cache=vc_d,
+                          q_norm_w=dev(qn) if qk_norm else None, k_norm_w=dev(kn) if qk_norm else None)
+    got_q = qkv_d[:, : H * d].reshape(T, H, d).cpu()
+    got_k = qkv_d[:, H * d: (H + Hkv) * d].reshape(T, Hkv, d).cpu()
+    if qk_norm:
+        ulp_close(got_q, q2, "bf16", ulps=2)
+        ulp_close(kc_d, kc, "bf16", ulps=2)
+    else:
+        assert torch.equal(got_q, q2) and torch.equal(got_k, k2)
+        assert torch.equal(kc_d.cpu(), kc)
+    assert torch.equal(vc_d.cpu(), vc), "the V copy is a byte copy"
+    assert torch.equal(qkv_d[:, (H + Hkv) * d:].cpu(), qkv[:, (H + Hkv) * d:]), "v must not be modified"
+
+
+def test_kv_store_strided_views_and_negative_slots():
+    from byox_vllm_amd import kernels
+    torch.manual_seed(2)
+    T, Hkv, d, bs, nb = 7, 2, 64, 16, 4
+    qkv = torch.randn(T, 6 * d).to(torch.float16)
+    k = qkv[:, 2 * d: 4 * d].view(T, Hkv, d)
+    v = qkv[:, 4 * d:].view(T, Hkv, d)
+    slots = torch.tensor([5, -1, 63, 0, -12, 17, 33], dtype=torch.int32)
+    kc, vc = torch.zeros(nb, bs, Hkv, d, dtype=torch.float16), torch.zeros(nb, bs, Hkv, d, dtype=torch.float16)
+    OA.store_kvcache(k, v, kc, vc, slots)
+    qd = dev(qkv)
+    kd, vd = dev(torch.zeros_like(kc)), dev(torch.zeros_like(vc))
+    kernels.kv_store(qd[:, 2 * d: 4 * d].view(T, Hkv, d), qd[:, 4 * d:].view(T, Hkv, d), kd, vd, dev(slots))
+    assert torch.equal(kd.cpu(), kc) and torch.equal(vd.cpu(), vc)
+
+
+def _paged_case(B, H, Hkv, D, bs, lens, dt, seed=0, extra_cols=2):
+    g = torch.Generator().manual_seed(seed)
+    nblk = sum(-(-n // bs) for n in lens) + 3
+    q = torch.randn(B, H, D, generator=g).to(dt)
+    kc = torch.randn(nblk, bs, Hkv, D, generator=g).to(dt)
+    vc = torch.randn(nblk, bs, Hkv, D, generator=g).to(dt)
+    perm = torch.randperm(nblk, generator=g).tolist()
+    width = max(-(-n // bs) for n in lens) + extra_cols
+    tables = torch.full((B, width), -1, dtype=torch.int32)
+    it = iter(perm)
+    for i, n in enumerate(lens):
+        for j in range(-(-n // bs)):
+            tables[i, j] = next(it)
+    return q, kc, vc, torch.tensor(lens, dtype=torch.int32), tables
+
+
+ATTN_TOL = {"bf16": 2e-2, "fp16": 3e-3}   # |O| <= ~4 here; P is rounded to the model dtype before P.V (as flash-attn does)
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("cfg", [
+    dict(B=5, H=14, Hkv=2, D=64, bs=16, lens=[1, 16, 17, 100, 257]),        # Qwen2-0.5B heads, tiny blocks, ragged
+    dict(B=3, H=28, Hkv=4, D=128, bs=256, lens=[255, 256, 700]),            # Qwen2-7B heads, production block size
+    dict(B=4, H=16, Hkv=8, D=128, bs=32, lens=[31, 32, 33, 64]),            # Qwen3-0.6B heads
+    dict(B=2, H=4, Hkv=4, D=64, bs=16, lens=[5, 48]),                       # MHA (group of 1)
+    dict(B=3, H=14, Hkv=2, D=64, bs=16, lens=[0, 40, 0]),                   # graph padding rows (context 0)
+])
+@pytest.mark.parametrize("splits", [1, 2, 5])
+def test_paged_decode_attention(name, cfg, splits):
+    from byox_vllm_amd import kernels
+    dt = DT[name]
+    q, kc, vc, ctx, tables = _paged_case(dt=dt, **cfg)
+    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5,
+                                    num_splits=splits)
+    err = (got.float().cpu() - want.float()).abs().max().item()
+    assert err <= ATTN_TOL[name], err
+    assert torch.isfinite(got.float()).all()
+
+
+def test_paged_decode_ignores_garbage_past_context():
+    """Slots past the context length may hold NaN/Inf bit patterns (recycled blocks): they must not leak."""
+    from byox_vllm_amd import kernels
+    q, kc, vc, ctx, tables = _paged_case(B=2, H=14, Hkv=2, D=64, bs=16, lens=[19, 35], dt=torch.bfloat16)
+    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, 0.125)
+    for b, n in enumerate([19, 35]):
+        blk, off = tables[b, n // 16].item(), n % 16
+        kc[blk, off:] = float("nan")
+        vc[blk, off:] = float("inf")
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), 0.125)
+    assert torch.isfinite(got.float()).all()
+    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+
+
+def test_paged_decode_softmax_rescale_branch():
+    """A key far larger than the running max late in the sequence forces the online-softmax rescale."""
+    from byox_vllm_amd import kernels
+    q, kc, vc, ctx, tables = _paged_case(B=1, H=14, Hkv=2, D=64, bs=16, lens=[200], dt=torch.bfloat16, seed=3)
+    blk = tables[0, 150 // 16].item()
+    kc[blk, 150 % 16] = (q[0, 0] * 6).to(torch.bfloat16)      # spike for head 0 at token 150
+    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, 0.125)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), 0.125)
+    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("cfg", [
+    dict(H=4, Hkv=2, D=64, lens=[5, 19, 64, 1]),
+    dict(H=14, Hkv=2, D=64, lens=[130, 33]),
+    dict(H=4, Hkv=1, D=128, lens=[70, 16, 17]),
+])
+def test_prefill_attention_packed(name, cfg):
+    from byox_vllm_amd import kernels
+    dt = DT[name]
+    g = torch.Generator().manual_seed(5)
+    T = sum(cfg["lens"])
+    H, Hkv, D = cfg["H"], cfg["Hkv"], cfg["D"]
+    qkv = torch.randn(T, (H + 2 * Hkv) * D, generator=g).to(dt)   # strided views, as the model passes them
+    q = qkv[:, : H * D].view(T, H, D)
+    k = qkv[:, H * D: (H + Hkv) * D].view(T, Hkv, D)
+    v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
+    cu = torch.tensor([0] + list(np.cumsum(cfg["lens"])), dtype=torch.int32)
+    want = OA.attn_varlen(q, k, v, cu, cu, D ** -0.5)
+    qd = dev(qkv)
+    got = kernels.attn_prefill(qd[:, : H * D].view(T, H, D), qd[:, H * D: (H + Hkv) * D].view(T, Hkv, D),
+                               qd[:, (H + Hkv) * D:].view(T, Hkv, D), dev(cu), dev(cu), max(cfg["lens"]), D ** -0.5)
+    err = (got.float().cpu() - want.float()).abs().max().item()
+    assert err <= ATTN_TOL[name], err
+
+
+def test_prefill_attention_prefix_cache_paged():
+    """seqlen_q < seqlen_k: keys come from the paged cache, mask aligned to the bottom-right corner."""
+    from byox_vllm_amd import kernels
+    dt, H, Hkv, D, bs = torch.bfloat16, 4, 2, 64, 16
+    k_lens, cached = [22, 40, 16 + 3], [16, 32, 16]
+    q_lens = [n - c for n, c in zip(k_lens, cached)]
+    _, kc, vc, _, tables = _paged_case(B=3, H=H, Hkv=Hkv, D=D, bs=bs, lens=k_lens, dt=dt, seed=8)
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(sum(q_lens), H, D, generator=g).to(dt)
+    cu_q = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(k_lens)), dtype=torch.int32)
+    want = OA.attn_varlen(q, kc, vc, cu_q, cu_k, D ** -0.5, tables)
+    got = kernels.attn_prefill(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(q_lens), D ** -0.5,
+                               block_tables=dev(tables))
+    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+
+
+GEMM_SHAPES = [(1, 128, 128), (7, 192, 256), (32, 1152, 896), (128, 896, 896), (130, 256, 384), (300, 64, 128)]
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("fmt", ["dense", "w8a16", "w4a16"])
+@pytest.mark.parametrize("split_k", [1, 3])
+def test_gemm_dense_and_dequant(name, M, N, K, fmt, split_k):
+    """nv_gemm == F.linear on the (dequantised) weight; fp32 accumulation, one rounding at the end."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    dt = DT[name]
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt)
+    lw = LinearWeight.make(dev(w), None if fmt == "dense" else fmt)
+    if fmt == "w4a16":
+        packed, scales = lw.logical_int4()
+        assert torch.equal(packed.cpu(), Q.quantize_w4(w)[0]) and torch.equal(scales.cpu(), Q.quantize_w4(w)[1])
+        w_ref = Q.dequantize_w4(packed.cpu(), scales.cpu())
+    elif fmt == "w8a16":
+        q8, scales = lw.logical_int8()
+        assert torch.equal(q8.cpu(), Q.quantize_w8(w)[0]) and torch.equal(scales.cpu(), Q.quantize_w8(w)[1])
+        w_ref = Q.dequantize_w8(q8.cpu(), scales.cpu())
+    else:
+        w_ref = w
+    want = torch.nn.functional.linear(x.double(), w_ref.double(), bias.double())   # exact up to fp64
+    got = kernels.gemm(dev(x), lw, dev(bias), split_k=split_k)
+    # fp32 accumulation error is far below one output rounding; allow 1 ulp of the output dtype
+    ulp_close(got, want.to(dt), name, ulps=1.0)
+
+
+def test_gemm_matches_cpu_flinear_closely():
+    """Against the oracle's own F.linear in bf16 (different summation order): same values up to the last bit."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(64, 896, generator=g).to(torch.bfloat16)
+    w = (torch.randn(1152, 896, generator=g) * 0.02).to(torch.bfloat16)
+    want = L.linear(x, w)
+    got = kernels.gemm(dev(x), LinearWeight.dense(dev(w)))
+    ulp_close(got, want, "bf16", ulps=1.0)
+
+
+def test_embed_gather_with_vocab_shard():
+    from byox_vllm_amd import kernels
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(64, 128, generator=g).to(torch.bfloat16)
+    ids = torch.tensor([0, 63, 64, 127, 70, 5])
+    for rank in (0, 1):
+        want = L.vocab_embedding(ids, w, rank, 2)
+        got = kernels.embed(dev(ids), dev(w), vocab_start=64 * rank)
+        assert torch.equal(got.cpu(), want)
+
+
+def test_sampler_replays_reference_draws(golden):
+    from byox_vllm_amd import kernels
+    g = golden.npz("sampler")
+    logits = dev(t(g["logits"], torch.bfloat16))
+    toks = kernels.sample(logits, dev(torch.from_numpy(g["temps"])), noise=dev(torch.from_numpy(g["noise"])))
+    assert toks.cpu().tolist() == g["tokens"].tolist()
+    greedy = kernels.sample(logits, dev(torch.zeros(6)))
+    assert greedy.cpu().tolist() == logits.float().argmax(-1).cpu().tolist()
+
+
+def test_sampler_large_vocab_greedy_and_distribution():
+    from byox_vllm_amd import kernels
+    g = torch.Generator().manual_seed(13)
+    logits = (torch.randn(8, 151936, generator=g) * 2).to(torch.bfloat16)
+    want = L.sample(logits, torch.zeros(8))
+    got = kernels.sample(dev(logits), dev(torch.zeros(8)))
+    assert got.cpu().tolist() == want.tolist()
+    # in-kernel Exp(1) noise: a two-token distribution with p = (0.75, 0.25) is sampled at about that rate
+    two = torch.full((4000, 64), -30.0)
+    two[:, 3], two[:, 9] = np.log(3.0), 0.0
+    toks = kernels.sample(dev(two.to(torch.bfloat16)), dev(torch.ones(4000)), seed=77).cpu()
+    assert set(toks.tolist()) <= {3, 9}
+    assert abs((toks == 3).float().mean().item() - 0.75) < 0.04
+
+
+def test_stage_decode_inputs_pads_like_reference():
+    from byox_vllm_amd import kernels
+    bs, padded, cols, gcols = 3, 8, 2, 5
+    g = dict(input_ids=dev(torch.full((8,), 7, dtype=torch.int64)), positions=dev(torch.full((8,), 7, dtype=torch.int64)),
+             slot_mapping=dev(torch.full((8,), 7, dtype=torch.int32)), context_lens=dev(torch.full((8,), 7, dtype=torch.int32)),
+             block_tables=dev(torch.full((8, gcols), 9, dtype=torch.int32)), padded_bs=padded)
+    ids, pos = torch.tensor([11, 12, 13]), torch.tensor([4, 5, 6])
+    slots, ctx = torch.tensor([40, 50, 60], dtype=torch.int32), torch.tensor([5, 6, 7], dtype=torch.int32)
+    bt = torch.tensor([[1, 2], [3, -1], [4, 5]], dtype=torch.int32)
+    kernels.stage_decode_inputs(dev(ids), dev(pos), dev(slots), dev(ctx), dev(bt), g)
+    assert g["input_ids"].cpu().tolist() == [11, 12, 13, 0, 0, 0, 0, 0]
+    assert g["slot_mapping"].cpu().tolist() == [40, 50, 60, -1, -1, -1, -1, -1]     # model_runner.py:248-249
+    assert g["context_lens"].cpu().tolist() == [5, 6, 7, 0, 0, 0, 0, 0]             # model_runner.py:250-251
+    assert g["block_tables"][:3, :2].cpu().tolist() == bt.tolist()
+    assert g["block_tables"][:, 2:].cpu().eq(9).all()                              # stale columns stay, as in the reference
+
+
+def test_bad_arguments_are_rejected_not_launched():
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    x = dev(torch.zeros(4, 100, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="nv_rmsnorm"):
+        kernels.rms_norm(x, dev(torch.ones(100, dtype=torch.bfloat16)), 1e-6)       # hidden % 8 != 0
+    with pytest.raises(RuntimeError, match="nv_gemm"):
+        kernels.gemm(dev(torch.zeros(4, 96, dtype=torch.bfloat16)), LinearWeight.dense(dev(torch.zeros(64, 96, dtype=torch.bfloat16))))
+    with pytest.raises(TypeError):
+        kernels.rms_norm(dev(torch.zeros(4, 128)), dev(torch.ones(128)), 1e-6)      # fp32 is not a HIP-path dtype
+    with pytest.raises(RuntimeError, match="no CPU compute path"):
+        kernels.rms_norm(torch.zeros(4, 128, dtype=torch.bfloat16), torch.ones(128, dtype=torch.bfloat16), 1e-6)
