@@ -1,0 +1,259 @@
+"""Decode-step benchmark of the paged-KV hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--parallelism dp|tp]
+
+A step = ModelRunner.run(seqs, is_prefill=False): host metadata -> hipGraph
+replay of the decode forward -> LM head -> sampler -> token ids on the host,
+for one batch of synthetic sequences whose KV cache (random values) is already
+resident in HBM.  Rank 0 prints ONE JSON line; `value` is whole-job decode
+tokens/s, `roofline` prices the paged-attention kernel against HBM peak and
+`cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+
+For N > 1 launch under torch.distributed.run (one rank per GPU).  `dp` runs one
+independent replica per GPU (no data-path collective; the 0.5B model's 14/2
+heads do not split 8 ways under the reference's sharding rules); `tp` shards
+the linears column/row-wise with RCCL all-reduce, as the reference does.
+"""
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (model, quantization, dtype, batch, context)
+    "qwen2-0.5b-w4a16-b128-s1024": ("qwen2-0.5b", "w4a16", "bf16", 128, 1024),
+    "qwen2-0.5b-bf16-b32-s1024": ("qwen2-0.5b", None, "bf16", 32, 1024),
+    "qwen2-0.5b-w8a16-b64-s1024": ("qwen2-0.5b", "w8a16", "bf16", 64, 1024),
+    "qwen2-7b-w4a16-b128-s1024": ("qwen2-7b", "w4a16", "bf16", 128, 1024),
+    "qwen2-7b-w4a16-b512-s1024": ("qwen2-7b", "w4a16", "bf16", 512, 1024),
+    "qwen2-0.5b-fp16-b1-s128": ("qwen2-0.5b", None, "fp16", 1, 128),
+}
+DEFAULT_WORKLOAD = "qwen2-0.5b-w4a16-b128-s1024"
+DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def make_sequences(batch, context, block_size, vocab_cap=10000, temperature=0.6):
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+    random.seed(0)
+    seqs = []
+    next_block = 0
+    for _ in range(batch):
+        ids = [random.randrange(vocab_cap) for _ in range(context)]
+        seq = Sequence(ids, block_size, SamplingParams(temperature=temperature, max_tokens=1 << 30, ignore_eos=True))
+        n = seq.num_blocks
+        seq.block_table = list(range(next_block, next_block + n))
+        next_block += n
+        seqs.append(seq)
+    return seqs, next_block
+
+
+class StepDriver:
+    """Advances every sequence by one token per step, handing out blocks as the scheduler would."""
+
+    def __init__(self, runner, seqs, next_block, tp=1):
+        self.runner, self.seqs, self.next_block, self.tp = runner, seqs, next_block, tp
+
+    def step(self):
+        tokens = self.runner.call("run", self.seqs, False)
+        if self.tp > 1:   # only TP rank 0 samples: every rank must feed the same ids into the next step
+            t = torch.tensor(tokens if tokens is not None else [0] * len(self.seqs), device="cuda")
+            dist.broadcast(t, src=0)
+            tokens = t.tolist()
+        for seq, tok in zip(self.seqs, tokens):
+            seq.append_token(tok)
+            if len(seq) % seq.block_size == 1:
+                seq.block_table.append(self.next_block)
+                self.next_block += 1
+
+
+def kv_bytes_per_launch(seqs, hf, tp):
+    """Algorithmic bytes one paged-attention launch (one layer) must read: K and V of every cached token."""
+    hkv = hf.num_key_value_heads // tp
+    return sum(len(s) for s in seqs) * 2 * hkv * hf.head_dim * hf.dtype.itemsize
+
+
+def step_bytes(runner, seqs, hf, tp):
+    """Algorithmic HBM bytes of one whole decode step on this GPU (weights + scales + LM head + KV read/write)."""
+    from byox_vllm_amd.layers.linear import LinearBase
+    w = sum(m.packed.nbytes for m in runner.model.modules() if isinstance(m, LinearBase))
+    head = runner.model.lm_head.weight.numel() * hf.dtype.itemsize
+    kv_read = kv_bytes_per_launch(seqs, hf, tp) * hf.num_hidden_layers
+    kv_write = len(seqs) * hf.num_hidden_layers * 2 * (hf.num_key_value_heads // tp) * hf.head_dim * hf.dtype.itemsize
+    return w + head + kv_read + kv_write
+
+
+def time_attention_kernel(runner, driver, steps):
+    """Per-launch duration of the paged-attention kernel(s), HIP events on the launch stream, in situ:
+    the step runs eagerly and every layer's attention call is bracketed by an event pair."""
+    from byox_vllm_amd.layers.attention import Attention
+    pairs = []
+    original = Attention.forward_fused
+
+    def timed(self, q, k, v, out=None):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        o = original(self, q, k, v, out)
+        b.record()
+        pairs.append((a, b))
+        return o
+
+    was_eager = runner.enforce_eager
+    runner.enforce_eager = True
+    Attention.forward_fused = timed
+    try:
+        for _ in range(steps):
+            driver.step()
+        torch.cuda.synchronize()
+    finally:
+        Attention.forward_fused = original
+        runner.enforce_eager = was_eager
+    ms = [a.elapsed_time(b) for a, b in pairs]
+    return sum(ms) / len(ms) * 1e-3, len(ms)
+
+
+def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0):
+    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample: a reduced batch, few steps."""
+    from byox_vllm_amd.config import qwen2_config
+    from oracle import model as OM
+    hf = qwen2_config(model_name, dtype=dtype)
+    sample_batch = min(batch, 8)
+    bs = 256
+    t0 = time.perf_counter()
+    weights = OM.random_weights(hf, seed=0)
+    if quantization:
+        weights = OM.fake_quantize(weights, 4 if quantization == "w4a16" else 8)
+    blocks_per_seq = (context + 8) // bs + 1
+    om = OM.OracleQwen(hf, weights, bs, sample_batch * blocks_per_seq)
+    for kv in om.kv:
+        kv.normal_()
+    tables = [list(range(i * blocks_per_seq, (i + 1) * blocks_per_seq)) for i in range(sample_batch)]
+    lens = [context] * sample_batch
+    ids = torch.randint(0, 10000, (sample_batch,))
+    setup = time.perf_counter() - t0
+    steps, spent = 0, 0.0
+    while steps < 1 or (spent < budget_s and steps < 4):
+        lens = [n + 1 for n in lens]
+        ctx, pos = OM.decode_ctx(lens, tables, bs)
+        t1 = time.perf_counter()
+        logits = om.compute_logits(om.forward(ids, pos, ctx), ctx)
+        ids = logits.float().argmax(-1)
+        spent += time.perf_counter() - t1
+        steps += 1
+    return {"value": round(sample_batch * steps / spent, 2), "unit": "tokens/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} decode steps, batch {sample_batch} of {batch}, context {context}, same model/format, "
+                      f"eager PyTorch CPU oracle (setup {setup:.0f}s not timed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
+    ap.add_argument("--kernel-steps", type=int, default=2, help="instrumented eager steps for the roofline figure")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from byox_vllm_amd.config import Config, qwen2_config
+    from byox_vllm_amd.engine.model_runner import ModelRunner
+
+    model_name, quantization, dtype_name, batch, context = WORKLOADS[args.workload]
+    hf = qwen2_config(model_name, dtype=DTYPES[dtype_name])
+    tp = world if (args.parallelism == "tp" and world > 1) else 1
+    if tp > 1:
+        assert hf.num_attention_heads % tp == 0 and hf.num_key_value_heads % tp == 0, (
+            f"{model_name}: {hf.num_attention_heads}/{hf.num_key_value_heads} heads do not split {tp} ways "
+            "under the reference's sharding rules; use --parallelism dp")
+    block_size = 256
+    total_steps = args.warmup + args.steps + args.kernel_steps + 2
+    blocks_per_seq = (context + total_steps) // block_size + 1
+    config = Config("synthetic", hf_config=hf, quantization=quantization, tensor_parallel_size=tp,
+                    kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
+                    max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
+                    max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
+                    enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp == 1 else 0)
+    runner = ModelRunner(config, rank if tp > 1 else 0, None)
+    runner.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
+    seqs, next_block = make_sequences(batch, context, block_size)
+    driver = StepDriver(runner, seqs, next_block, tp)
+
+    for _ in range(args.warmup):
+        driver.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        driver.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    replicas = world // tp
+    tokens = batch * args.steps * replicas
+    bytes_step = step_bytes(runner, seqs, hf, tp)
+    kern_s, launches = time_attention_kernel(runner, driver, args.kernel_steps)
+    kv_bytes = kv_bytes_per_launch(seqs, hf, tp)
+    achieved = kv_bytes / kern_s / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "decode tokens/s",
+            "value": round(tokens / elapsed, 1),
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
+            "dtype": dtype_name, "data": "synthetic (random weights, random KV history, random prompts)",
+            "config": {"workload": args.workload, "model": model_name, "weight_format": quantization or dtype_name,
+                       "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
+                       "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": not args.eager,
+                       "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
+            "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_algorithmic_bytes": bytes_step,
+            "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ decode_combine_kernel)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": kv_bytes, "avg_launch_us": round(kern_s * 1e6, 2), "launches_timed": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline and (model_name != "qwen2-7b" or args.cpu_baseline_7b):
+            line["cpu_baseline"] = cpu_baseline(model_name, quantization, DTYPES[dtype_name], batch, context)
+        print(json.dumps(line), flush=True)
+    runner.exit()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

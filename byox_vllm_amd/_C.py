@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libnv_hip.so")
 
 NV_BF16, NV_F16 = 0, 1
 W_DENSE, W_INT8, W_INT4 = 0, 1, 2
+GEMM_SILU_MUL, GEMM_PARTIAL_OUT = 1, 2
 
 _p, _i, _i64, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
@@ -23,6 +24,8 @@ _PROTOS = {
     "nv_last_error": (C.c_char_p, []),
     "nv_rmsnorm": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _f, _i, _p]),
     "nv_add_rmsnorm": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
+    "nv_add_rmsnorm_splitk": (_i, [_p, _i, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
+    "nv_rope_kv_store_splitk": (_i, [_p, _i, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _f, _i64, _i, _i, _i, _i, _p]),
     "nv_rope_kv_store": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _f, _i64, _i, _i, _i, _i, _p]),
     "nv_kv_store": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i, _i, _p]),
     "nv_paged_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -33,7 +36,8 @@ _PROTOS = {
     "nv_gemm_workspace_bytes": (_sz, [_i64, _i, _i]),
     "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),
     "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
-    "nv_sample": (_i, [_p, _i64, _p, _p, _p, _i, _i, _u64, _i, _p]),
+    "nv_sample_workspace_bytes": (_sz, [_i]),
+    "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _i, _p]),
     "nv_stage_decode_inputs": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

@@ -56,6 +56,7 @@ class Config:
     num_kvcache_blocks: int = -1
     quantization: str | None = None
     seed: int = 0
+    graph_batch_sizes: Any = None   # optional list: capture decode graphs only for these padded batch sizes
     state_dict: Any = None   # optional in-memory checkpoint keyed by the packed parameter names
 
     def __post_init__(self):

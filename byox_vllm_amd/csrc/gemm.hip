@@ -49,7 +49,7 @@ __device__ __forceinline__ typename VecOf<T>::x8 dequant_w8(uint32_t lo, uint32_
   return f;
 }
 
-template <typename T, int WFMT, int BM>
+template <typename T, int WFMT, int BM, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split
 __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                    const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
 
   // ---- epilogue: lane holds columns ncol + 4g .. +3 of rows m0 + 16 i + c
   const int nb = ncol + 4 * g;
-  if (split_k == 1) {
+  if constexpr (EPI == 0) {
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
       const u32x2 t = *reinterpret_cast<const u32x2*>(bias + nb);
@@ -184,6 +184,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint16_t* __restrict__ 
         o[0] = pack2<T>(acc[i][0] + b4[0], acc[i][1] + b4[1]);
         o[1] = pack2<T>(acc[i][2] + b4[2], acc[i][3] + b4[3]);
         *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+      }
+    }
+  } else if constexpr (EPI == 1) {
+    // rows of W were interleaved so that a lane's 4 columns are (gate j, gate j+1, up j, up j+1):
+    // out[m][j] = dtype(dtype(silu(dtype(gate))) * dtype(up)), the roundings eager PyTorch performs
+    const int j0 = (ncol >> 1) + 2 * g;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t m = m0 + 16 * i + c;
+      if (m < M) {
+        float r[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float gt = bits_to_f32<T>(f32_to_bits<T>(acc[i][e]));
+          const float up = bits_to_f32<T>(f32_to_bits<T>(acc[i][2 + e]));
+          const float sl = bits_to_f32<T>(f32_to_bits<T>(gt / (1.0f + expf(-gt))));
+          r[e] = sl * up;
+        }
+        *reinterpret_cast<uint32_t*>(out + m * out_stride + j0) = pack2<T>(r[0], r[1]);
       }
     }
   } else {
@@ -221,17 +240,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 extern "C" size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k) {
-  if (split_k <= 1) return 0;
+  if (split_k < 1) split_k = 1;
   return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
-template <typename T, int WFMT>
+template <typename T, int WFMT, int EPI>
 static void launch_gemm(int bm, dim3 grid, hipStream_t s, const void* x, int64_t xs, const void* w, const void* scales,
                         const void* bias, void* out, int64_t os, float* partial, int64_t M, int N, int K, int split_k) {
-#define GO(BMV)                                                                                                      \
-  gemm_kernel<T, WFMT, BMV><<<grid, dim3(256), 0, s>>>((const uint16_t*)x, xs, w, (const uint16_t*)scales,          \
-                                                       (const uint16_t*)bias, (uint16_t*)out, os, partial, M, N, K, \
-                                                       split_k)
+#define GO(BMV)                                                                                                        \
+  gemm_kernel<T, WFMT, BMV, EPI><<<grid, dim3(256), 0, s>>>((const uint16_t*)x, xs, w, (const uint16_t*)scales,      \
+                                                            (const uint16_t*)bias, (uint16_t*)out, os, partial, M, N, \
+                                                            K, split_k)
   switch (bm) {
     case 16: GO(16); break;
     case 32: GO(32); break;
@@ -241,13 +260,23 @@ static void launch_gemm(int bm, dim3 grid, hipStream_t s, const void* x, int64_t
 #undef GO
 }
 
+template <typename T, int WFMT>
+static void launch_gemm_epi(int epi, int bm, dim3 grid, hipStream_t s, const void* x, int64_t xs, const void* w,
+                            const void* scales, const void* bias, void* out, int64_t os, float* partial, int64_t M,
+                            int N, int K, int split_k) {
+  if (epi == 0) launch_gemm<T, WFMT, 0>(bm, grid, s, x, xs, w, scales, bias, out, os, partial, M, N, K, split_k);
+  else if (epi == 1) launch_gemm<T, WFMT, 1>(bm, grid, s, x, xs, w, scales, bias, out, os, partial, M, N, K, split_k);
+  else launch_gemm<T, WFMT, 2>(bm, grid, s, x, xs, w, scales, bias, out, os, partial, M, N, K, split_k);
+}
+
 extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
                        void* out, int64_t out_row_stride, int64_t M, int N, int K, int wfmt, int split_k,
                        void* workspace, size_t workspace_bytes, int flags, int dtype, nv_stream_t stream) {
-  NV_CHECK_ARG(x && w && out, "nv_gemm: null pointer");
+  const bool silu = (flags & NV_GEMM_SILU_MUL) != 0, slabs_out = (flags & NV_GEMM_PARTIAL_OUT) != 0;
+  NV_CHECK_ARG(x && w && (out || slabs_out), "nv_gemm: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_gemm: bad dtype %d", dtype);
   NV_CHECK_ARG(wfmt == NV_W_DENSE || wfmt == NV_W_INT8 || wfmt == NV_W_INT4, "nv_gemm: bad weight format %d", wfmt);
-  NV_CHECK_ARG(flags == 0, "nv_gemm: unsupported flags %d", flags);
+  NV_CHECK_ARG((flags & ~(NV_GEMM_SILU_MUL | NV_GEMM_PARTIAL_OUT)) == 0 && !(silu && slabs_out), "nv_gemm: unsupported flags %d", flags);
   NV_CHECK_ARG(N > 0 && N % GEMM_BN == 0, "nv_gemm: N=%d must be a multiple of %d", N, GEMM_BN);
   NV_CHECK_ARG(K > 0 && K % GEMM_BK == 0, "nv_gemm: K=%d must be a multiple of %d", K, GEMM_BK);
   NV_CHECK_ARG(wfmt == NV_W_DENSE || scales, "nv_gemm: quantised weights need scales");
@@ -255,10 +284,13 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)out % 8 == 0 && (!bias || (uintptr_t)bias % 8 == 0),
                "nv_gemm: misaligned pointer");
   NV_CHECK_ARG(M >= 0, "nv_gemm: M=%lld", (long long)M);
+  NV_CHECK_ARG(!silu || !bias, "nv_gemm: the silu*up epilogue takes no bias");
   if (M == 0) return NV_OK;
   if (split_k < 1) split_k = 1;
   if (split_k > K / GEMM_BK) split_k = K / GEMM_BK;
-  const size_t need = nv_gemm_workspace_bytes(M, N, split_k);
+  if (silu) split_k = 1;
+  const bool use_slabs = slabs_out || split_k > 1;
+  const size_t need = use_slabs ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
   NV_CHECK_ARG(need == 0 || (workspace && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0),
                "nv_gemm: workspace %zu bytes < %zu needed", workspace_bytes, need);
   const int bm = M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128));
@@ -267,19 +299,20 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   dim3 grid(N / GEMM_BN, (unsigned)mtiles, split_k);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
+  const int epi = use_slabs ? 2 : (silu ? 1 : 0);
 #define DISPATCH(TT)                                                                                                   \
   do {                                                                                                                 \
     if (wfmt == NV_W_DENSE)                                                                                            \
-      launch_gemm<TT, NV_W_DENSE>(bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k); \
+      launch_gemm_epi<TT, NV_W_DENSE>(epi, bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k); \
     else if (wfmt == NV_W_INT8)                                                                                        \
-      launch_gemm<TT, NV_W_INT8>(bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k);  \
+      launch_gemm_epi<TT, NV_W_INT8>(epi, bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k);  \
     else                                                                                                               \
-      launch_gemm<TT, NV_W_INT4>(bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k);  \
+      launch_gemm_epi<TT, NV_W_INT4>(epi, bm, grid, s, x, x_row_stride, w, scales, bias, out, out_row_stride, partial, M, N, K, split_k);  \
   } while (0)
   if (dtype == NV_BF16) DISPATCH(bf16_t); else DISPATCH(f16_t);
 #undef DISPATCH
   NV_CHECK_LAUNCH();
-  if (split_k > 1) {
+  if (use_slabs && !slabs_out) {
     const int64_t total = M * (N / 4);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -87,6 +87,10 @@ extern "C" int nv_embed(const int64_t* ids, const void* weight, void* out, int64
 }
 
 // ---------------------------------------------------------------- sampler
+// argmax_v softmax(l/T)_v / e_v  ==  argmax_v (l_v / T - log e_v): the softmax normaliser and the
+// row maximum are common to the row, and log is monotonic, so one pass over the logits suffices.
+// Stage 1: grid (splits, B), each workgroup scans a slice of the row with 16-byte loads and writes
+// its best (score, index); stage 2: one wavefront per row picks the winner (lowest index on ties).
 __device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -101,75 +105,115 @@ struct Best {
 __device__ __forceinline__ Best better(Best a, Best b) {
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
-
-template <typename T>
-__global__ __launch_bounds__(1024) void sample_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
-                                                      const float* __restrict__ temps, const float* __restrict__ noise,
-                                                      int64_t* __restrict__ tokens, int V, uint64_t seed) {
-  __shared__ float s_val[16];
-  __shared__ int s_idx[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-  const uint16_t* row = logits + (int64_t)b * row_stride;
-  const float temp = temps[b];
-  const bool greedy = temp == 0.0f;
-  float mx = -INFINITY;
-  if (!greedy) {  // row max of logits / T
-    for (int v = tid; v < V; v += blockDim.x) mx = fmaxf(mx, bits_to_f32<T>(row[v]) / temp);
-    mx = wave_max(mx);
-    if (lane == 0) s_val[wid] = mx;
-    __syncthreads();
-    mx = s_val[0];
-    for (int w = 1; w < nw; ++w) mx = fmaxf(mx, s_val[w]);
-    __syncthreads();
-  }
-  Best best = {-INFINITY, 0x7fffffff};
-  for (int v = tid; v < V; v += blockDim.x) {
-    const float l = bits_to_f32<T>(row[v]);
-    float score;
-    if (greedy) {
-      score = l;
-    } else {
-      float e;
-      if (noise) {
-        e = noise[(int64_t)b * V + v];
-      } else {  // Exp(1) = -log(U), U uniform in (0, 1]
-        const uint32_t r = mix32(seed ^ ((uint64_t)b << 32) ^ (uint64_t)v);
-        e = -logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f));
-      }
-      // softmax's normaliser is common to the row and cannot change the argmax
-      score = expf(l / temp - mx) / fmaxf(e, 1e-10f);
-    }
-    best = better(best, Best{score, v});
-  }
+__device__ __forceinline__ Best wave_best(Best best) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     Best other = {__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
     best = better(best, other);
   }
+  return best;
+}
+
+#define SAMPLE_SPLITS 8
+
+template <typename T>
+__device__ __forceinline__ float sample_score(float l, int b, int v, int V, float inv_temp, bool greedy,
+                                              const float* __restrict__ noise, uint64_t seed) {
+  if (greedy) return l;
+  float e;
+  if (noise) {
+    e = noise[(int64_t)b * V + v];
+  } else {  // Exp(1) = -log(U), U uniform in (0, 1]
+    const uint32_t r = mix32(seed ^ ((uint64_t)b << 32) ^ (uint64_t)v);
+    e = -__logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f));
+  }
+  return l * inv_temp - __logf(fmaxf(e, 1e-10f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_partial_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                             const float* __restrict__ temps,
+                                                             const float* __restrict__ noise, float* __restrict__ pv,
+                                                             int* __restrict__ pi, int V, uint64_t seed) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint16_t* row = logits + (int64_t)b * row_stride;
+  const float temp = temps[b];
+  const bool greedy = temp == 0.0f;
+  const float inv_temp = greedy ? 1.0f : 1.0f / temp;
+  // slice of the row in 8-element vectors (rows are 16-byte aligned when V % 8 == 0 and the stride allows)
+  const bool vec_ok = (V % 8 == 0) && (row_stride % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
+  Best best = {-INFINITY, 0x7fffffff};
+  if (vec_ok) {
+    const int nvec = V >> 3;
+    const int per = (nvec + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
+    const int v0 = blockIdx.x * per;
+    int v1 = v0 + per;
+    if (v1 > nvec) v1 = nvec;
+    for (int i = v0 + tid; i < v1; i += 256) {
+      const u32x4 t = reinterpret_cast<const u32x4*>(row)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = i * 8 + 2 * j;
+        best = better(best, Best{sample_score<T>(lo_f32<T>(t[j]), b, v, V, inv_temp, greedy, noise, seed), v});
+        best = better(best, Best{sample_score<T>(hi_f32<T>(t[j]), b, v + 1, V, inv_temp, greedy, noise, seed), v + 1});
+      }
+    }
+  } else {
+    const int per = (V + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
+    const int v0 = blockIdx.x * per;
+    int v1 = v0 + per;
+    if (v1 > V) v1 = V;
+    for (int v = v0 + tid; v < v1; v += 256)
+      best = better(best, Best{sample_score<T>(bits_to_f32<T>(row[v]), b, v, V, inv_temp, greedy, noise, seed), v});
+  }
+  best = wave_best(best);
   if (lane == 0) {
     s_val[wid] = best.v;
     s_idx[wid] = best.i;
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < nw; ++w) best = better(best, Best{s_val[w], s_idx[w]});
-    tokens[b] = best.i;
+    for (int w = 1; w < 4; ++w) best = better(best, Best{s_val[w], s_idx[w]});
+    pv[b * SAMPLE_SPLITS + blockIdx.x] = best.v;
+    pi[b * SAMPLE_SPLITS + blockIdx.x] = best.i;
   }
 }
 
+__global__ __launch_bounds__(256) void sample_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                           int64_t* __restrict__ tokens, int B) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  Best best = {-INFINITY, 0x7fffffff};
+  if (lane < SAMPLE_SPLITS) best = Best{pv[b * SAMPLE_SPLITS + lane], pi[b * SAMPLE_SPLITS + lane]};
+  best = wave_best(best);
+  if (lane == 0) tokens[b] = best.i;
+}
+
+extern "C" size_t nv_sample_workspace_bytes(int B) { return (size_t)B * SAMPLE_SPLITS * 8; }
+
 extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
-                         int64_t* tokens, int B, int V, uint64_t seed, int dtype, nv_stream_t stream) {
+                         int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
+                         int dtype, nv_stream_t stream) {
   NV_CHECK_ARG(logits && temperatures && tokens, "nv_sample: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_sample: bad dtype %d", dtype);
-  NV_CHECK_ARG(V > 0 && B >= 0, "nv_sample: bad shape B=%d V=%d", B, V);
+  NV_CHECK_ARG(V > 0 && B >= 0 && B <= 65535, "nv_sample: bad shape B=%d V=%d", B, V);
   if (B == 0) return NV_OK;
+  NV_CHECK_ARG(workspace && workspace_bytes >= nv_sample_workspace_bytes(B) && (uintptr_t)workspace % 4 == 0,
+               "nv_sample: workspace %zu bytes < %zu needed", workspace_bytes, nv_sample_workspace_bytes(B));
   hipStream_t s = (hipStream_t)stream;
+  float* pv = (float*)workspace;
+  int* pi = (int*)(pv + (size_t)B * SAMPLE_SPLITS);
+  dim3 grid(SAMPLE_SPLITS, B);
   if (dtype == NV_BF16)
-    sample_kernel<bf16_t><<<dim3(B), dim3(1024), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
-                                                         noise, tokens, V, seed);
+    sample_partial_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
+                                                             noise, pv, pi, V, seed);
   else
-    sample_kernel<f16_t><<<dim3(B), dim3(1024), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, noise,
-                                                        tokens, V, seed);
+    sample_partial_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
+                                                            noise, pv, pi, V, seed);
+  NV_CHECK_LAUNCH();
+  sample_final_kernel<<<dim3((B + 3) / 4), dim3(256), 0, s>>>(pv, pi, tokens, B);
   NV_CHECK_LAUNCH();
   return NV_OK;
 }

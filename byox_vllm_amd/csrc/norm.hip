@@ -4,11 +4,24 @@
 // rows are a few KB, so the second pass over the row is served by the CU's L1.
 #include "common.h"
 
-template <typename T, bool ADD>
+// x as the GEMM would have written it: the split-K slabs summed in slab order, rounded to the model dtype.
+template <typename T>
+__device__ __forceinline__ u32x4 sum_partials(const float* __restrict__ part, int64_t slab, int nparts, int64_t off) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(part + off);
+  f32x4 b = *reinterpret_cast<const f32x4*>(part + off + 4);
+  for (int z = 1; z < nparts; ++z) {
+    a += *reinterpret_cast<const f32x4*>(part + z * slab + off);
+    b += *reinterpret_cast<const f32x4*>(part + z * slab + off + 4);
+  }
+  return u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
+}
+
+template <typename T, bool ADD, bool PARTIAL>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const uint16_t* res,
                                                       const uint16_t* __restrict__ w, uint16_t* out,
                                                       uint16_t* res_out, int64_t rows, int hidden,
-                                                      int64_t x_stride, int64_t out_stride, float eps) {
+                                                      int64_t x_stride, int64_t out_stride, float eps,
+                                                      const float* __restrict__ part, int nparts) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -19,9 +32,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const u
   const u32x4* wv = reinterpret_cast<const u32x4*>(w);
   u32x4* ov = reinterpret_cast<u32x4*>(out + row * out_stride);
 
+  const int64_t slab = rows * hidden;
   float ss = 0.f;
   for (int i = lane; i < nvec; i += 64) {
-    u32x4 a = xv[i];
+    u32x4 a = PARTIAL ? sum_partials<T>(part, slab, nparts, row * hidden + 8 * i) : xv[i];
     u32x4 b = {0, 0, 0, 0};
     if (ADD) b = rv[i];
 #pragma unroll
@@ -39,7 +53,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const u
   const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
 
   for (int i = lane; i < nvec; i += 64) {
-    u32x4 a = xv[i];
+    u32x4 a = PARTIAL ? sum_partials<T>(part, slab, nparts, row * hidden + 8 * i) : xv[i];
     u32x4 b = {0, 0, 0, 0};
     if (ADD) b = rv[i];
     u32x4 ww = wv[i];
@@ -62,17 +76,20 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const u
   }
 }
 
-template <bool ADD>
+template <bool ADD, bool PARTIAL = false>
 static int launch_norm(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
-                       int hidden, int64_t xs, int64_t os, float eps, int dtype, hipStream_t s) {
+                       int hidden, int64_t xs, int64_t os, float eps, int dtype, hipStream_t s,
+                       const float* part = nullptr, int nparts = 0) {
   if (rows == 0) return NV_OK;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == NV_BF16)
-    rmsnorm_kernel<bf16_t, ADD><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w,
-                                                       (uint16_t*)out, (uint16_t*)res_out, rows, hidden, xs, os, eps);
+    rmsnorm_kernel<bf16_t, ADD, PARTIAL><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res,
+                                                                (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out,
+                                                                rows, hidden, xs, os, eps, part, nparts);
   else
-    rmsnorm_kernel<f16_t, ADD><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w,
-                                                      (uint16_t*)out, (uint16_t*)res_out, rows, hidden, xs, os, eps);
+    rmsnorm_kernel<f16_t, ADD, PARTIAL><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res,
+                                                               (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out,
+                                                               rows, hidden, xs, os, eps, part, nparts);
   NV_CHECK_LAUNCH();
   return NV_OK;
 }
@@ -97,4 +114,17 @@ extern "C" int nv_add_rmsnorm(const void* x, const void* residual, const void* w
                "nv_add_rmsnorm: pointers must be 16-byte aligned");
   return launch_norm<true>(x, residual, weight, out, residual_out, rows, hidden, hidden, hidden, eps, dtype,
                            (hipStream_t)stream);
+}
+
+extern "C" int nv_add_rmsnorm_splitk(const float* partials, int num_partials, const void* residual, const void* weight,
+                                     void* out, void* residual_out, int64_t rows, int hidden, float eps, int dtype,
+                                     nv_stream_t stream) {
+  NV_CHECK_ARG(partials && residual && weight && out && residual_out, "nv_add_rmsnorm_splitk: null pointer");
+  NV_CHECK_ARG(num_partials >= 1, "nv_add_rmsnorm_splitk: num_partials=%d", num_partials);
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_add_rmsnorm_splitk: bad dtype %d", dtype);
+  NV_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "nv_add_rmsnorm_splitk: hidden=%d must be a positive multiple of 8", hidden);
+  NV_CHECK_ARG(((uintptr_t)partials | (uintptr_t)out | (uintptr_t)weight | (uintptr_t)residual | (uintptr_t)residual_out) % 16 == 0,
+               "nv_add_rmsnorm_splitk: pointers must be 16-byte aligned");
+  return launch_norm<true, true>(nullptr, residual, weight, out, residual_out, rows, hidden, hidden, hidden, eps, dtype,
+                                 (hipStream_t)stream, partials, num_partials);
 }

@@ -8,14 +8,15 @@
 // cross-lane traffic; the per-head norm is one wave reduction.
 #include "common.h"
 
-template <typename T>
+template <typename T, bool PARTIAL>
 __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride,
                                                       const int64_t* __restrict__ positions,
                                                       const float* __restrict__ cos_sin,
                                                       const int32_t* __restrict__ slots, uint16_t* k_cache,
                                                       uint16_t* v_cache, const uint16_t* __restrict__ qn_w,
                                                       const uint16_t* __restrict__ kn_w, float eps, int64_t ntok, int H,
-                                                      int Hkv, int D) {
+                                                      int Hkv, int D, const float* __restrict__ part, int nparts,
+                                                      const uint16_t* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int heads = H + 2 * Hkv;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -27,11 +28,27 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
   const bool is_q = hs < H, is_k = !is_q && hs < H + Hkv;
   const int slot = slots ? slots[t] : -1;
 
-  if (!is_q && !is_k) {  // v head: copy to the cache
-    if (v_cache && slot >= 0) {
-      uint16_t* dst = v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D;
-      for (int i = lane; i < (D >> 1); i += 64)
-        reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(row)[i];
+  // PARTIAL: the qkv row does not exist yet; build this head from the GEMM's split-K slabs (+ bias),
+  // rounded to the model dtype exactly as the GEMM epilogue would have stored it.
+  const int ncols = heads * D;
+  auto from_partials = [&](int col) -> uint16_t {
+    float a = 0.f;
+    for (int z = 0; z < nparts; ++z) a += part[((int64_t)z * ntok + t) * ncols + col];
+    if (bias) a += bits_to_f32<T>(bias[col]);
+    return f32_to_bits<T>(a);
+  };
+
+  if (!is_q && !is_k) {  // v head: copy to the cache (and materialise it in the qkv buffer)
+    uint16_t* dst = (v_cache && slot >= 0) ? v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D : nullptr;
+    for (int i = lane; i < D; i += 64) {
+      uint16_t val;
+      if (PARTIAL) {
+        val = from_partials(hs * D + i);
+        row[i] = val;
+      } else {
+        val = row[i];
+      }
+      if (dst) dst[i] = val;
     }
     return;
   }
@@ -42,8 +59,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
   const bool act = lane < half;
   float x1 = 0.f, x2 = 0.f;
   if (act) {
-    x1 = bits_to_f32<T>(row[lane]);
-    x2 = bits_to_f32<T>(row[lane + half]);
+    x1 = bits_to_f32<T>(PARTIAL ? from_partials(hs * D + lane) : row[lane]);
+    x2 = bits_to_f32<T>(PARTIAL ? from_partials(hs * D + lane + half) : row[lane + half]);
   }
   if (nw) {  // per-head RMSNorm (Qwen3): fp32 normalise, round, scale by weight in the model dtype
     float ss = wave_sum(x1 * x1 + x2 * x2);
@@ -88,10 +105,10 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const uint16_t* __restric
   }
 }
 
-extern "C" int nv_rope_kv_store(void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
-                                const int32_t* slot_mapping, void* k_cache, void* v_cache, const void* q_norm_w,
-                                const void* k_norm_w, float eps, int64_t T, int H, int Hkv, int D, int dtype,
-                                nv_stream_t stream) {
+static int rope_launch(void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                       const int32_t* slot_mapping, void* k_cache, void* v_cache, const void* q_norm_w,
+                       const void* k_norm_w, float eps, int64_t T, int H, int Hkv, int D, int dtype,
+                       const float* partials, int num_partials, const void* bias, nv_stream_t stream) {
   NV_CHECK_ARG(qkv && positions && cos_sin, "nv_rope_kv_store: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_rope_kv_store: bad dtype %d", dtype);
   NV_CHECK_ARG(D == 64 || D == 128 || D == 32 || D == 16, "nv_rope_kv_store: head_dim %d not in {16,32,64,128}", D);
@@ -104,16 +121,34 @@ extern "C" int nv_rope_kv_store(void* qkv, int64_t qkv_row_stride, const int64_t
   const int64_t items = T * (H + 2 * Hkv);
   dim3 grid((unsigned)((items + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == NV_BF16)
-    rope_kv_kernel<bf16_t><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, positions, cos_sin, slot_mapping,
-                                                  (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,
-                                                  (const uint16_t*)k_norm_w, eps, T, H, Hkv, D);
-  else
-    rope_kv_kernel<f16_t><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, positions, cos_sin, slot_mapping,
-                                                 (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,
-                                                 (const uint16_t*)k_norm_w, eps, T, H, Hkv, D);
+#define ROPE_GO(TT, PP)                                                                                               \
+  rope_kv_kernel<TT, PP><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, positions, cos_sin, slot_mapping,    \
+                                                (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,   \
+                                                (const uint16_t*)k_norm_w, eps, T, H, Hkv, D, partials, num_partials, \
+                                                (const uint16_t*)bias)
+  if (dtype == NV_BF16) { if (partials) ROPE_GO(bf16_t, true); else ROPE_GO(bf16_t, false); }
+  else                  { if (partials) ROPE_GO(f16_t, true); else ROPE_GO(f16_t, false); }
+#undef ROPE_GO
   NV_CHECK_LAUNCH();
   return NV_OK;
+}
+
+extern "C" int nv_rope_kv_store(void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                                const int32_t* slot_mapping, void* k_cache, void* v_cache, const void* q_norm_w,
+                                const void* k_norm_w, float eps, int64_t T, int H, int Hkv, int D, int dtype,
+                                nv_stream_t stream) {
+  return rope_launch(qkv, qkv_row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, q_norm_w, k_norm_w, eps,
+                     T, H, Hkv, D, dtype, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int nv_rope_kv_store_splitk(const float* partials, int num_partials, const void* bias, void* qkv,
+                                       int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                                       const int32_t* slot_mapping, void* k_cache, void* v_cache, const void* q_norm_w,
+                                       const void* k_norm_w, float eps, int64_t T, int H, int Hkv, int D, int dtype,
+                                       nv_stream_t stream) {
+  NV_CHECK_ARG(partials && num_partials >= 1, "nv_rope_kv_store_splitk: no partials");
+  return rope_launch(qkv, qkv_row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, q_norm_w, k_norm_w, eps,
+                     T, H, Hkv, D, dtype, partials, num_partials, bias, stream);
 }
 
 extern "C" int nv_kv_store(const void* key, int64_t key_row_stride, const void* value, int64_t value_row_stride,

@@ -49,7 +49,10 @@ class ModelRunner:
         if self.world_size > 1 and not dist.is_initialized():
             dist.init_process_group("nccl", "tcp://127.0.0.1:2333", world_size=self.world_size, rank=rank)
             self._own_pg = True
-        local = rank % max(torch.cuda.device_count(), 1)
+        import os
+        from byox_vllm_amd.layers.linear import set_tp
+        set_tp(rank if self.world_size > 1 else 0, self.world_size, getattr(config, "tp_group", None))
+        local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         self.device = torch.device("cuda", local)
         default_dtype = torch.get_default_dtype()
@@ -208,7 +211,7 @@ class ModelRunner:
                 start = seq.block_table[i] * bs
                 slot_mapping.extend(range(start, start + (bs if i != last else seq.last_block_num_tokens)))
         block_tables = self._prepare_block_tables(seqs, device) if cu_k[-1] > cu_q[-1] else None  # prefix hit
-        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt), device)  # noqa: E731
+        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt, device="cpu"), device)  # noqa: E731
         set_context(True, to(cu_q, torch.int32), to(cu_k, torch.int32), max_q, max_k,
                     to(slot_mapping, torch.int32), None, block_tables)
         return to(input_ids, torch.int64), to(positions, torch.int64)
@@ -219,14 +222,14 @@ class ModelRunner:
         positions = [len(seq) - 1 for seq in seqs]
         context_lens = [len(seq) for seq in seqs]
         slot_mapping = [seq.block_table[-1] * bs + seq.last_block_num_tokens - 1 for seq in seqs]
-        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt), device)  # noqa: E731
+        to = lambda data, dt: self._to_device(torch.tensor(data, dtype=dt, device="cpu"), device)  # noqa: E731
         slot_t, ctx_t = to(slot_mapping, torch.int32), to(context_lens, torch.int32)
         block_tables = self._prepare_block_tables(seqs) if device is None else self._prepare_block_tables(seqs, device)
         set_context(False, slot_mapping=slot_t, context_lens=ctx_t, block_tables=block_tables)
         return to(input_ids, torch.int64), to(positions, torch.int64)
 
     def _prepare_sample(self, seqs: list[Sequence]):
-        return self._to_device(torch.tensor([seq.temperature for seq in seqs], dtype=torch.float32))
+        return self._to_device(torch.tensor([seq.temperature for seq in seqs], dtype=torch.float32, device="cpu"))
 
     # ------------------------------------------------------------------ forward
     @torch.inference_mode()
@@ -297,7 +300,8 @@ class ModelRunner:
             outputs=torch.zeros(max_bs, hf.hidden_size, dtype=hf.dtype, device=dev),
             padded_bs=max_bs,
         )
-        self.graph_bs = graph_batch_sizes(max_bs)
+        self.graph_bs = sorted(config.graph_batch_sizes) if config.graph_batch_sizes else graph_batch_sizes(max_bs)
+        max_bs = self.graph_bs[-1]
         self.max_graph_bs = max_bs
         self.graphs, self.graph_pool = {}, None
         for bs in reversed(self.graph_bs):

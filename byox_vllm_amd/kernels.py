@@ -27,6 +27,14 @@ def workspace(nbytes: int, device, tag: str = "main") -> torch.Tensor:
     return ws
 
 
+class Partials:
+    """Split-K output of nv_gemm left as fp32 slabs [n, M, N] in the GEMM workspace, plus the bias still to add.
+    Valid until the next gemm() that writes slabs; consumed by add_rms_norm / rope_kv_store."""
+
+    def __init__(self, slabs, n, rows, cols, bias, dtype):
+        self.slabs, self.n, self.rows, self.cols, self.bias, self.dtype = slabs, n, rows, cols, bias, dtype
+
+
 def rms_norm(x, weight, eps, out=None):
     require_gpu(x, "rms_norm")
     hidden = x.size(-1)
@@ -39,6 +47,14 @@ def rms_norm(x, weight, eps, out=None):
 
 
 def add_rms_norm(x, residual, weight, eps, out=None, residual_out=None):
+    if isinstance(x, Partials):
+        assert x.bias is None and residual.is_contiguous() and residual.shape == (x.rows, x.cols)
+        out = torch.empty_like(residual) if out is None else out
+        residual_out = residual if residual_out is None else residual_out
+        check(lib().nv_add_rmsnorm_splitk(ptr(x.slabs), x.n, ptr(residual), ptr(weight), ptr(out), ptr(residual_out),
+                                          x.rows, x.cols, eps, dtype_code(residual.dtype), stream()),
+              "nv_add_rmsnorm_splitk")
+        return out, residual_out
     require_gpu(x, "add_rms_norm")
     hidden = x.size(-1)
     assert x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
@@ -52,7 +68,13 @@ def add_rms_norm(x, residual, weight, eps, out=None, residual_out=None):
 
 def rope_kv_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, slot_mapping=None,
                   k_cache=None, v_cache=None, q_norm_w=None, k_norm_w=None, eps=1e-6):
-    """Rotate q and k inside ``qkv`` [T, (H+2Hkv)*D] in place; optionally store k/v into the paged cache."""
+    """Rotate q and k inside ``qkv`` [T, (H+2Hkv)*D] in place; optionally store k/v into the paged cache.
+    ``qkv`` may be the QKV GEMM's Partials: the summed, biased qkv row is then materialised first."""
+    partials = None
+    if isinstance(qkv, Partials):
+        partials = qkv
+        assert partials.cols == (num_heads + 2 * num_kv_heads) * head_dim
+        qkv = torch.empty(partials.rows, partials.cols, dtype=partials.dtype, device=partials.slabs.device)
     require_gpu(qkv, "rope_kv_store")
     T = qkv.size(0)
     assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.size(1) >= (num_heads + 2 * num_kv_heads) * head_dim
@@ -62,6 +84,13 @@ def rope_kv_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, sl
         assert slot_mapping is not None and slot_mapping.dtype == torch.int32 and slot_mapping.numel() == T
         assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == qkv.dtype
         assert k_cache.size(-1) == head_dim and k_cache.size(-2) == num_kv_heads
+    if partials is not None:
+        check(lib().nv_rope_kv_store_splitk(ptr(partials.slabs), partials.n, ptr(partials.bias), ptr(qkv),
+                                            qkv.stride(0), ptr(positions), ptr(cos_sin), ptr(slot_mapping),
+                                            ptr(k_cache), ptr(v_cache), ptr(q_norm_w), ptr(k_norm_w), eps, T,
+                                            num_heads, num_kv_heads, head_dim, dtype_code(qkv.dtype), stream()),
+              "nv_rope_kv_store_splitk")
+        return qkv
     check(lib().nv_rope_kv_store(ptr(qkv), qkv.stride(0), ptr(positions), ptr(cos_sin), ptr(slot_mapping),
                                  ptr(k_cache), ptr(v_cache), ptr(q_norm_w), ptr(k_norm_w), eps, T,
                                  num_heads, num_kv_heads, head_dim, dtype_code(qkv.dtype), stream()),
@@ -143,23 +172,37 @@ def pick_split_k(M, N, K, target_blocks=256):
     return max(1, min(K // 128, target_blocks // max(tiles, 1)))
 
 
-def gemm(x, w, bias=None, out=None, split_k=None):
-    """x [M, K] @ w^T where ``w`` is a layers.quant.LinearWeight (dense, int8 or int4)."""
+def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=False):
+    """x [M, K] @ w^T where ``w`` is a layers.quant.LinearWeight (dense, int8 or int4).
+
+    silu_mul: ``w`` holds gate/up rows interleaved (LinearWeight.interleave_gate_up); returns silu(gate)*up [M, N/2].
+    partial_out: return the split-K slabs as a Partials for a fused consumer instead of reducing them here."""
     require_gpu(x, "gemm")
     M, K = x.shape
     assert K == w.in_features and x.stride(1) == 1 and x.dtype == w.dtype
     N = w.out_features
-    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
-    assert out.stride(1) == 1 and out.size(1) == N
     if bias is not None:
         assert bias.numel() == N and bias.dtype == x.dtype
     if split_k is None:
-        split_k = pick_split_k(M, N, K)
-    nbytes = lib().nv_gemm_workspace_bytes(M, N, split_k)
-    ws = workspace(nbytes, x.device, "gemm") if nbytes else None
-    check(lib().nv_gemm(ptr(x), x.stride(0), ptr(w.data), ptr(w.scales), ptr(bias), ptr(out), out.stride(0),
-                        M, N, K, w.fmt, split_k, ptr(ws), ws.numel() if ws is not None else 0, 0,
+        split_k = 1 if silu_mul else pick_split_k(M, N, K)
+    split_k = max(1, min(split_k, K // 128))
+    if split_k == 1:
+        partial_out = False   # nothing to fuse: the GEMM epilogue writes the finished rows itself
+    flags = (_C.GEMM_SILU_MUL if silu_mul else 0) | (_C.GEMM_PARTIAL_OUT if partial_out else 0)
+    ws = None
+    if split_k > 1 or partial_out:
+        ws = workspace(lib().nv_gemm_workspace_bytes(M, N, split_k), x.device, "gemm")
+    if partial_out:
+        out_ptr, out_stride = None, N
+    else:
+        out = torch.empty(M, N // 2 if silu_mul else N, dtype=x.dtype, device=x.device) if out is None else out
+        assert out.stride(1) == 1 and out.size(1) == (N // 2 if silu_mul else N)
+        out_ptr, out_stride = ptr(out), out.stride(0)
+    check(lib().nv_gemm(ptr(x), x.stride(0), ptr(w.data), ptr(w.scales), None if partial_out else ptr(bias), out_ptr,
+                        out_stride, M, N, K, w.fmt, split_k, ptr(ws), ws.numel() if ws is not None else 0, flags,
                         dtype_code(x.dtype), stream()), "nv_gemm")
+    if partial_out:
+        return Partials(ws, split_k, M, N, bias, x.dtype)
     return out
 
 
@@ -180,8 +223,9 @@ def sample(logits, temperatures, noise=None, seed=0, out=None):
     if noise is not None:
         assert noise.dtype == torch.float32 and noise.shape == logits.shape and noise.is_contiguous()
     out = torch.empty(B, dtype=torch.int64, device=logits.device) if out is None else out
-    check(lib().nv_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(noise), ptr(out), B, V,
-                          seed & 0xFFFFFFFFFFFFFFFF, dtype_code(logits.dtype), stream()), "nv_sample")
+    ws = workspace(lib().nv_sample_workspace_bytes(B), logits.device, "sample")
+    check(lib().nv_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(noise), ptr(out), ptr(ws), ws.numel(),
+                          B, V, seed & 0xFFFFFFFFFFFFFFFF, dtype_code(logits.dtype), stream()), "nv_sample")
     return out
 
 

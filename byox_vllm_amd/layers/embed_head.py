@@ -5,7 +5,7 @@ import torch.distributed as dist
 from torch import nn
 
 from byox_vllm_amd import kernels
-from byox_vllm_amd.layers.linear import _tp
+from byox_vllm_amd.layers.linear import _tp, tp_group
 from byox_vllm_amd.layers.quant import LinearWeight
 from byox_vllm_amd.utils.context import get_context
 
@@ -30,7 +30,7 @@ class VocabParallelEmbedding(nn.Module):
         # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
         y = kernels.embed(x, self.weight.data, self.vocab_start_idx)
         if self.tp_size > 1:
-            dist.all_reduce(y)
+            dist.all_reduce(y, group=tp_group())
         return y
 
 
@@ -47,6 +47,8 @@ class ParallelLMHead(VocabParallelEmbedding):
         logits = kernels.gemm(x, LinearWeight.dense(self.weight.data))
         if self.tp_size > 1:
             gathered = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-            dist.gather(logits, gathered, 0)
+            group = tp_group()
+            dst = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.gather(logits, gathered, dst, group=group)
             logits = torch.cat(gathered, -1) if self.tp_rank == 0 else None
         return logits

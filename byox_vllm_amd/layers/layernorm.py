@@ -15,8 +15,10 @@ class RMSNorm(nn.Module):
     def rms_forward(self, x: torch.Tensor) -> torch.Tensor:
         return kernels.rms_norm(x.contiguous(), self.weight.data, self.eps)
 
-    def add_rms_forward(self, x: torch.Tensor, residual: torch.Tensor):
-        # in place on both buffers: x becomes the normed output, residual the new residual
+    def add_rms_forward(self, x, residual: torch.Tensor):
+        # x may be a kernels.Partials (split-K slabs of the preceding linear).  The residual is updated in place.
+        if isinstance(x, kernels.Partials):
+            return kernels.add_rms_norm(x, residual, self.weight.data, self.eps, residual_out=residual)
         return kernels.add_rms_norm(x, residual, self.weight.data, self.eps, out=x, residual_out=residual)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):

@@ -20,8 +20,23 @@ def divide(numerator, denominator):
     return numerator // denominator
 
 
+_TP_STATE = None   # (rank, size, process group) once the runner has fixed the tensor-parallel layout
+
+
+def set_tp(rank: int, size: int, group=None) -> None:
+    """Fix the tensor-parallel layout explicitly (a data-parallel job has a process group but TP size 1)."""
+    global _TP_STATE
+    _TP_STATE = (rank, size, group)
+
+
+def tp_group():
+    return _TP_STATE[2] if _TP_STATE is not None else None
+
+
 def _tp():
-    if dist.is_available() and dist.is_initialized():
+    if _TP_STATE is not None:
+        return _TP_STATE[0], _TP_STATE[1]
+    if dist.is_available() and dist.is_initialized():   # the reference's rule: TP = the default group
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 
@@ -46,10 +61,10 @@ class LinearBase(nn.Module):
         if quantization is not None:
             self.weight = None
 
-    def _gemm(self, x, bias, out=None):
+    def _gemm(self, x, bias, out=None, **kw):
         if self.packed is None:
             self.finalize(None)
-        return kernels.gemm(x, self.packed, bias, out=out)
+        return kernels.gemm(x, self.packed, bias, out=out, **kw)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
@@ -75,14 +90,34 @@ class ColumnParallelLinear(LinearBase):
         shard = param.data.size(self.tp_dim)
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
 
-    def forward(self, x, out=None):
-        return self._gemm(x, None if self.bias is None else self.bias.data, out=out)
+    def forward(self, x, out=None, partial_out=False):
+        """partial_out: hand the split-K slabs (and the bias) to a fused consumer instead of reducing here."""
+        return self._gemm(x, None if self.bias is None else self.bias.data, out=out, partial_out=partial_out)
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
     def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False):
         self.output_sizes = output_sizes
+        self.fused_silu = False
         super().__init__(input_size, sum(output_sizes), bias)
+
+    def finalize(self, quantization: str | None = None, fuse_silu: bool = False) -> None:
+        """fuse_silu: store gate/up rows interleaved so forward_silu_mul() can apply SiluAndMul in the GEMM epilogue."""
+        from byox_vllm_amd.layers.quant import interleave_gate_up
+        self.fused_silu = fuse_silu and self.bias is None and len(self.output_sizes) == 2
+        w = interleave_gate_up(self.weight.data) if self.fused_silu else self.weight.data
+        self.packed = LinearWeight.make(w, quantization)
+        if quantization is not None or self.fused_silu:
+            self.weight = None
+
+    def forward(self, x, out=None, partial_out=False):
+        assert not self.fused_silu, "weights are stored for the fused epilogue: call forward_silu_mul"
+        return super().forward(x, out=out, partial_out=partial_out)
+
+    def forward_silu_mul(self, x, out=None):
+        """silu(gate) * up in one launch -> [T, intermediate / tp]."""
+        assert self.fused_silu
+        return self._gemm(x, None, out=out, silu_mul=True)
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: int):
         offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
@@ -121,9 +156,12 @@ class RowParallelLinear(LinearBase):
         shard = param.data.size(self.tp_dim)
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, partial_out=False):
+        """partial_out (single rank only): return the split-K slabs for the following add_rmsnorm to sum."""
         bias = self.bias.data if (self.bias is not None and self.tp_rank == 0) else None
+        if partial_out and self.tp_size == 1 and bias is None:
+            return self._gemm(x, None, partial_out=True)
         y = self._gemm(x, bias, out=out)
         if self.tp_size > 1:
-            dist.all_reduce(y)
+            dist.all_reduce(y, group=tp_group())
         return y

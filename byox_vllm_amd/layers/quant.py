@@ -42,6 +42,17 @@ def _scales(w: torch.Tensor, qmax: int):
     return g, s
 
 
+def interleave_gate_up(w: torch.Tensor) -> torch.Tensor:
+    """[gate; up] rows -> rows 4i..4i+3 = (gate 2i, gate 2i+1, up 2i, up 2i+1): the row order
+    nv_gemm's silu(gate)*up epilogue expects (a lane of the MFMA result owns 4 consecutive rows)."""
+    gate, up = w.chunk(2, 0)
+    inter = gate.size(0)
+    assert inter % 2 == 0
+    g = gate.reshape(inter // 2, 2, -1)
+    u = up.reshape(inter // 2, 2, -1)
+    return torch.cat((g, u), dim=1).reshape(2 * inter, -1).contiguous()
+
+
 class LinearWeight:
     """What nv_gemm consumes: ``fmt``, ``data`` (device tensor), ``scales`` ([K/128, N] or None)."""
 

@@ -56,10 +56,10 @@ class Qwen3Attention(nn.Module):
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         context = get_context()
-        qkv = self.qkv_proj(hidden_states)
+        qkv = self.qkv_proj(hidden_states, partial_out=True)   # split-K slabs + bias, summed inside the RoPE kernel
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0
-        kernels.rope_kv_store(
+        qkv = kernels.rope_kv_store(
             qkv, positions, self.rotary_emb.cos_sin_cache, self.num_heads, self.num_kv_heads, self.head_dim,
             slot_mapping=context.slot_mapping if has_cache else None,
             k_cache=attn.k_cache if has_cache else None, v_cache=attn.v_cache if has_cache else None,
@@ -70,7 +70,7 @@ class Qwen3Attention(nn.Module):
         k = k.view(-1, self.num_kv_heads, self.head_dim)
         v = v.view(-1, self.num_kv_heads, self.head_dim)
         o = attn.forward_fused(q, k, v)
-        return self.o_proj(o.view(o.size(0), -1))
+        return self.o_proj(o.view(o.size(0), -1), partial_out=True)
 
 
 class Qwen3MLP(nn.Module):
@@ -82,7 +82,11 @@ class Qwen3MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x):
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        if self.gate_up_proj.fused_silu:
+            act = self.gate_up_proj.forward_silu_mul(x)
+        else:
+            act = self.act_fn(self.gate_up_proj(x))
+        return self.down_proj(act, partial_out=True)
 
 
 class Qwen3DecoderLayer(nn.Module):
@@ -156,5 +160,7 @@ class Qwen3ForCausalLM(nn.Module):
         """Convert every layer linear to its kernel-side weight (the LM head and embedding stay dense)."""
         from byox_vllm_amd.layers.linear import LinearBase
         for module in self.modules():
-            if isinstance(module, LinearBase):
+            if isinstance(module, MergedColumnParallelLinear):
+                module.finalize(quantization, fuse_silu=True)
+            elif isinstance(module, LinearBase):
                 module.finalize(quantization)

@@ -58,6 +58,14 @@ int nv_rmsnorm(const void* x, const void* weight, void* out, int64_t rows, int h
 int nv_add_rmsnorm(const void* x, const void* residual, const void* weight, void* out, void* residual_out,
                    int64_t rows, int hidden, float eps, int dtype, nv_stream_t stream);
 
+/* nv_add_rmsnorm whose x operand is still the split-K output of nv_gemm
+ * (NV_GEMM_PARTIAL_OUT): x = to_dtype(sum of the num_partials fp32 slabs [rows, hidden]),
+ * then exactly nv_add_rmsnorm.  Fuses RowParallelLinear's output (linear.py:143-147,
+ * single rank) into the next add_rms_forward. */
+int nv_add_rmsnorm_splitk(const float* partials, int num_partials, const void* residual, const void* weight,
+                          void* out, void* residual_out, int64_t rows, int hidden, float eps, int dtype,
+                          nv_stream_t stream);
+
 /* RotaryEmbedding.forward + store_kvcache (+ Qwen3 q_norm/k_norm) fused —
  * nanovllm/layers/rotary_embedding.py:37-48, layers/attention.py:10-49,
  * models/qwen3.py:76-83.
@@ -70,6 +78,15 @@ int nv_rope_kv_store(void* qkv, int64_t qkv_row_stride, const int64_t* positions
                      const int32_t* slot_mapping, void* k_cache, void* v_cache,
                      const void* q_norm_w, const void* k_norm_w, float eps,
                      int64_t T, int H, int Hkv, int D, int dtype, nv_stream_t stream);
+
+/* nv_rope_kv_store whose qkv operand is still the split-K output of the QKV GEMM:
+ * qkv = to_dtype(sum of slabs [T, (H+2Hkv)*D] + bias), written to `qkv` (q, k rotated;
+ * v as is), then as nv_rope_kv_store.  bias may be NULL. */
+int nv_rope_kv_store_splitk(const float* partials, int num_partials, const void* bias, void* qkv,
+                            int64_t qkv_row_stride, const int64_t* positions, const float* cos_sin,
+                            const int32_t* slot_mapping, void* k_cache, void* v_cache,
+                            const void* q_norm_w, const void* k_norm_w, float eps,
+                            int64_t T, int H, int Hkv, int D, int dtype, nv_stream_t stream);
 
 /* store_kvcache — nanovllm/layers/attention.py:10-49 (stand-alone form).
  * Copies key[t] / value[t] (row_elems = Hkv*D contiguous elements, row strides
@@ -115,11 +132,18 @@ int nv_silu_mul(const void* x, void* out, int64_t T, int I, int dtype, nv_stream
  * reference has no quantised path, its dense F.linear on the dequantised weight
  * is the oracle).  scales: [K/128, N] in the model dtype for int8/int4, else NULL.
  * K % 128 == 0, N % 64 == 0 for int8/int4; K % 32 == 0, N % 16 == 0 for dense.
- * split_k > 1 spreads K over that many workgroups; workspace must then hold
- * nv_gemm_workspace_bytes(M, N, split_k) bytes.
- * flags: NV_GEMM_SILU_MUL — W rows are gate/up interleaved in 16-row groups and
- * the epilogue writes silu(gate)*up, out is [M, N/2]. */
+ * split_k > 1 spreads K over that many workgroups, each writing an fp32 slab
+ * [M, N] into the workspace (nv_gemm_workspace_bytes(M, N, split_k) bytes), summed
+ * in slab order by a second kernel.
+ * flags:
+ *   NV_GEMM_SILU_MUL    W rows are interleaved so that rows 4i..4i+3 are (gate 2i,
+ *                       gate 2i+1, up 2i, up 2i+1); the epilogue writes
+ *                       silu(gate)*up (SiluAndMul, activation.py:10-13), out is [M, N/2].
+ *   NV_GEMM_PARTIAL_OUT leave the split_k fp32 slabs in the workspace (no bias, no
+ *                       reduce, `out` unused): the consumer kernel sums them
+ *                       (nv_add_rmsnorm_splitk, nv_rope_kv_store_splitk). */
 #define NV_GEMM_SILU_MUL 1
+#define NV_GEMM_PARTIAL_OUT 2
 size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k);
 int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
             void* out, int64_t out_row_stride, int64_t M, int N, int K, int wfmt, int split_k,
@@ -133,10 +157,13 @@ int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int h
 /* Sampler.forward — nanovllm/layers/sampler.py:11-15.
  * token[b] = argmax_v softmax(logits[b]/T[b])_v / max(noise[b, v], 1e-10); noise is
  * Exp(1): read from `noise` (fp32 [B, V]) when given, else drawn in-kernel from
- * (seed, b, v).  T[b] == 0 takes argmax(logits[b]) (greedy extension).  Ties
- * resolve to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V. */
+ * (seed, b, v).  Evaluated as argmax_v (logits/T - log noise), which has the same
+ * maximiser.  T[b] == 0 takes argmax(logits[b]) (greedy extension).  Ties resolve
+ * to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V. */
+size_t nv_sample_workspace_bytes(int B);
 int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
-              int64_t* tokens, int B, int V, uint64_t seed, int dtype, nv_stream_t stream);
+              int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed, int dtype,
+              nv_stream_t stream);
 
 /* Graph-replay staging — nanovllm/engine/model_runner.py:246-252 as ONE launch:
  * copies the step's ids/positions/slots/context_lens/block_tables into the

@@ -275,6 +275,59 @@ def test_gemm_dense_and_dequant(name, M, N, K, fmt, split_k):
     ulp_close(got, want.to(dt), name, ulps=1.0)
 
 
+@pytest.mark.parametrize("fmt", ["dense", "w4a16"])
+@pytest.mark.parametrize("M", [5, 128])
+def test_gemm_silu_mul_epilogue(fmt, M):
+    """gate_up GEMM with SiluAndMul in the epilogue == oracle linear -> silu_and_mul (eager roundings)."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    g = torch.Generator().manual_seed(21)
+    K, inter = 256, 192
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inter, K, generator=g) * 0.05).to(torch.bfloat16)
+    w_ref = w if fmt == "dense" else Q.dequantize_w4(*Q.quantize_w4(w))
+    want = L.silu_and_mul(L.linear(x, w_ref))
+    lw = LinearWeight.make(interleave_gate_up(dev(w)), None if fmt == "dense" else fmt)
+    got = kernels.gemm(dev(x), lw, silu_mul=True)
+    assert got.shape == (M, inter)
+    ulp_close(got, want, "bf16", ulps=2.0)
+
+
+def test_splitk_partials_feed_add_rmsnorm_and_rope():
+    """Slabs left by the GEMM, summed inside the consumer kernels, give what GEMM -> consumer gives."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    g = torch.Generator().manual_seed(22)
+    M, K, hid = 37, 512, 128
+    x = dev(torch.randn(M, K, generator=g).to(torch.bfloat16))
+    w = dev((torch.randn(hid, K, generator=g) * 0.05).to(torch.bfloat16))
+    res = dev(torch.randn(M, hid, generator=g).to(torch.bfloat16))
+    nw = dev((1 + 0.1 * torch.randn(hid, generator=g)).to(torch.bfloat16))
+    lw = LinearWeight.dense(w)
+    y = kernels.gemm(x, lw, split_k=4)
+    want_out, want_res = kernels.add_rms_norm(y, res.clone(), nw, 1e-6)
+    parts = kernels.gemm(x, lw, split_k=4, partial_out=True)
+    assert isinstance(parts, kernels.Partials) and parts.n == 4
+    got_res = res.clone()
+    got_out, _ = kernels.add_rms_norm(parts, got_res, nw, 1e-6)
+    assert torch.equal(got_out, want_out) and torch.equal(got_res, want_res)
+    # qkv slabs + bias -> rope + cache store
+    H, Hkv, d, T = 2, 1, 64, 9
+    wq = dev((torch.randn((H + 2 * Hkv) * d, K, generator=g) * 0.05).to(torch.bfloat16))
+    bq = dev((torch.randn((H + 2 * Hkv) * d, generator=g) * 0.1).to(torch.bfloat16))
+    xq = dev(torch.randn(T, K, generator=g).to(torch.bfloat16))
+    pos = dev(torch.arange(3, 3 + T))
+    slots = dev(torch.tensor([0, 1, 2, -1, 20, 21, 22, 23, 40], dtype=torch.int32))
+    table = dev(L.build_cos_sin_cache(d, 64, 1e6))
+    caches = [dev(torch.zeros(4, 16, Hkv, d, dtype=torch.bfloat16)) for _ in range(4)]
+    lq = LinearWeight.dense(wq)
+    want = kernels.rope_kv_store(kernels.gemm(xq, lq, bq, split_k=2), pos, table, H, Hkv, d, slot_mapping=slots,
+                                 k_cache=caches[0], v_cache=caches[1])
+    got = kernels.rope_kv_store(kernels.gemm(xq, lq, bq, split_k=2, partial_out=True), pos, table, H, Hkv, d,
+                                slot_mapping=slots, k_cache=caches[2], v_cache=caches[3])
+    assert torch.equal(got, want) and torch.equal(caches[0], caches[2]) and torch.equal(caches[1], caches[3])
+
+
 def test_gemm_matches_cpu_flinear_closely():
     """Against the oracle's own F.linear in bf16 (different summation order): same values up to the last bit."""
     from byox_vllm_amd import kernels
