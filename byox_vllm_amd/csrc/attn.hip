@@ -25,6 +25,8 @@
 // split s takes chunks s*4+w, s*4+w+4*splits, ...; the 4 partial results are
 // merged through LDS and, when splits > 1, per-split partials (fp32 O, max,
 // sum) go to the workspace for a small combine kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
@@ -34,11 +36,6 @@ template <int D> struct AttnGeom {
   static constexpr int NM = D / 16;   // MFMAs of the O^T product == d values per lane load
 };
 
-// One lane's view of where a 16-token tile lives.
-struct TileAddr {
-  int64_t row;   // first cache/packed row of the tile
-};
-
 template <typename T, int D>
 struct AttnState {
   float m;                                   // running max (log2 domain), same in the 4 lanes of a column
@@ -46,30 +43,29 @@ struct AttnState {
   f32x4 acc[AttnGeom<D>::NM];
 };
 
-// Loads for one 32-token chunk and the two MFMA products.
-//  k_base/v_base: pointer to element [row 0][this kv head][0]; row_stride in elements
-//  rows[2]: first row of tile 0 / tile 1 (wave-uniform)
-//  limit: number of visible keys for this lane's column; base: first token of the chunk
+// Registers holding one 32-token chunk of K (as MFMA A fragments) and V (row pieces).
+template <typename T, int D>
+struct ChunkRegs {
+  typename VecOf<T>::x8 kf[2][AttnGeom<D>::KS];
+  uint32_t vv[8][AttnGeom<D>::NM / 2];       // token slot j: NM consecutive d values starting at NM*c
+};
+
+// Issue the loads of one chunk.  k_base/v_base point at element [row 0][this kv head][0], row_stride in
+// elements; rows[2] = first row of tile 0 / tile 1 (wave-uniform).  TAIL clamps rows to max_row (packed keys).
 template <typename T, int D, bool TAIL>
-__device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS],
-                                           const uint16_t* k_base, const uint16_t* v_base, int64_t row_stride,
-                                           const int64_t (&rows)[2], int64_t max_row, int base, int limit, int n_keys,
-                                           float scale2) {
+__device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k_base, const uint16_t* v_base,
+                                           int64_t row_stride, const int64_t (&rows)[2], int64_t max_row) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-
-  // ---- issue all loads of the chunk: K as A-operand fragments, V rows
-  frag_t kf[2][KS];
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     int64_t krow = rows[tl] + c;
     if (TAIL && krow > max_row) krow = max_row;   // packed keys: never read past the buffer
     const uint16_t* kr = k_base + krow * row_stride + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[tl][ks] = *reinterpret_cast<const frag_t*>(kr + 32 * ks);
+    for (int ks = 0; ks < KS; ++ks) r.kf[tl][ks] = *reinterpret_cast<const frag_t*>(kr + 32 * ks);
   }
-  uint32_t vv[8][NM / 2];   // token j: NM consecutive d values starting at NM*c
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int off = (j < 4) ? (4 * g + j) : (4 * g + j - 4);
@@ -78,12 +74,24 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
     const uint16_t* vr = v_base + vrow * row_stride + NM * c;
     if constexpr (NM == 8) {
       const u32x4 t = *reinterpret_cast<const u32x4*>(vr);
-      vv[j][0] = t[0]; vv[j][1] = t[1]; vv[j][2] = t[2]; vv[j][3] = t[3];
+      r.vv[j][0] = t[0]; r.vv[j][1] = t[1]; r.vv[j][2] = t[2]; r.vv[j][3] = t[3];
     } else {
       const u32x2 t = *reinterpret_cast<const u32x2*>(vr);
-      vv[j][0] = t[0]; vv[j][1] = t[1];
+      r.vv[j][0] = t[0]; r.vv[j][1] = t[1];
     }
   }
+}
+
+// The two MFMA products and the online softmax for one loaded chunk.
+//  limit: number of visible keys for this lane's column; base: first token of the chunk;
+//  n_keys: keys at or past it may hold junk (TAIL zeroes their V rows).
+template <typename T, int D, bool TAIL>
+__device__ __forceinline__ void chunk_compute(AttnState<T, D>& st, ChunkRegs<T, D>& r,
+                                              const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS], int base, int limit,
+                                              int n_keys, float scale2) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
 
   // ---- S^T = K . Q^T
   f32x4 s[2];
@@ -91,7 +99,7 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
   for (int tl = 0; tl < 2; ++tl) {
     s[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s[tl] = mfma16(kf[tl][ks], qf[ks], s[tl]);
+    for (int ks = 0; ks < KS; ++ks) s[tl] = mfma16(r.kf[tl][ks], qf[ks], s[tl]);
   }
 
   // ---- online softmax, column-local
@@ -99,11 +107,11 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tok = base + 16 * tl + 4 * g + r;
-      float x = s[tl][r] * scale2;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int tok = base + 16 * tl + 4 * g + rr;
+      float x = s[tl][rr] * scale2;
       x = (tok < limit) ? x : -INFINITY;
-      s[tl][r] = x;
+      s[tl][rr] = x;
       cmax = fmaxf(cmax, x);
     }
   cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
@@ -116,10 +124,10 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = exp2f(s[tl][r] - m_use);
+    for (int rr = 0; rr < 4; ++rr) {
+      const float p = exp2f(s[tl][rr] - m_use);
       psum += p;
-      pf[tl * 4 + r] = (T)p;
+      pf[tl * 4 + rr] = (T)p;
     }
   st.m = m_new;
   st.l = st.l * alpha + psum;
@@ -133,7 +141,7 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
       const int tok = base + ((j < 4) ? (4 * g + j) : (16 + 4 * g + j - 4));
       if (tok >= n_keys) {
 #pragma unroll
-        for (int e = 0; e < NM / 2; ++e) vv[j][e] = 0u;
+        for (int e = 0; e < NM / 2; ++e) r.vv[j][e] = 0u;
       }
     }
   }
@@ -142,11 +150,21 @@ __device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename V
     u32x4 w;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const uint32_t a = vv[2 * jj][m >> 1], b = vv[2 * jj + 1][m >> 1];
+      const uint32_t a = r.vv[2 * jj][m >> 1], b = r.vv[2 * jj + 1][m >> 1];
       w[jj] = (m & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
     }
     st.acc[m] = mfma16(__builtin_bit_cast(frag_t, w), pf, st.acc[m]);
   }
+}
+
+template <typename T, int D, bool TAIL>
+__device__ __forceinline__ void attn_chunk(AttnState<T, D>& st, const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS],
+                                           const uint16_t* k_base, const uint16_t* v_base, int64_t row_stride,
+                                           const int64_t (&rows)[2], int64_t max_row, int base, int limit, int n_keys,
+                                           float scale2) {
+  ChunkRegs<T, D> r;
+  chunk_load<T, D, TAIL>(r, k_base, v_base, row_stride, rows, max_row);
+  chunk_compute<T, D, TAIL>(st, r, qf, base, limit, n_keys, scale2);
 }
 
 // Row index (in units of cache rows) of the first token of the 16-token tile that starts at `tok`.
@@ -157,8 +175,10 @@ __device__ __forceinline__ int64_t paged_tile_row(const int32_t* bt_row, int tok
 }
 
 // ------------------------------------------------------------------ decode
-template <typename T, int D>
-__global__ __launch_bounds__(256) void paged_decode_kernel(
+// NW wavefronts per workgroup share one (sequence, kv head, split); wavefront w takes chunks
+// split*NW + w, + NW*splits, ...  Loads run one chunk ahead of the MFMAs and block-table lookups two ahead.
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, const int32_t* __restrict__ block_tables, int bt_stride,
     const int32_t* __restrict__ context_lens, uint16_t* __restrict__ out, int64_t out_stride,
@@ -166,12 +186,13 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     int splits) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
-  __shared__ float s_acc[4][NM * 4][64];
-  __shared__ float s_m[4][16];
-  __shared__ float s_l[4][16];
+  __shared__ float s_acc[NW][NM * 4][64];
+  __shared__ float s_m[NW][16];
+  __shared__ float s_l[NW][16];
 
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the address math scalar
   const int G = H / Hkv;
   const int n_keys = context_lens[b];
   const int64_t row_stride = (int64_t)Hkv * D;
@@ -199,20 +220,35 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   for (int m = 0; m < NM; ++m) st.acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int n_chunks = (n_keys + 31) >> 5;
-  const int stride_chunks = splits * 4;
-  for (int ch = split * 4 + wid; ch < n_chunks; ch += stride_chunks) {
+  const int step = splits * NW;
+  // rows of a chunk's two tiles; a tile that starts past the end re-reads the chunk's first tile (masked anyway)
+  auto lookup = [&](int ch, int64_t (&rows)[2]) {
     const int base = ch << 5;
-    int64_t rows[2];
     rows[0] = paged_tile_row(bt_row, base, block_size);
-    // a second tile that starts past the end re-reads tile 0 (masked anyway)
     rows[1] = (base + 16 < n_keys) ? paged_tile_row(bt_row, base + 16, block_size) : rows[0];
-    if (base + 32 <= n_keys)
-      attn_chunk<T, D, false>(st, qf, k_base, v_base, row_stride, rows, INT64_MAX, base, n_keys, n_keys, scale2);
-    else
-      attn_chunk<T, D, true>(st, qf, k_base, v_base, row_stride, rows, INT64_MAX, base, n_keys, n_keys, scale2);
+  };
+  int ch = split * NW + wid;
+  if (ch < n_chunks) {
+    int64_t rows_cur[2], rows_nxt[2] = {0, 0};
+    lookup(ch, rows_cur);
+    if (ch + step < n_chunks) lookup(ch + step, rows_nxt);
+    ChunkRegs<T, D> cur, nxt;
+    chunk_load<T, D, false>(cur, k_base, v_base, row_stride, rows_cur, INT64_MAX);
+    for (; ch < n_chunks; ch += step) {
+      const bool has_next = ch + step < n_chunks;
+      int64_t rows_nn[2] = {0, 0};
+      if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
+      if (has_next) chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
+      const int base = ch << 5;
+      if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, cur, qf, base, n_keys, n_keys, scale2);
+      else chunk_compute<T, D, true>(st, cur, qf, base, n_keys, n_keys, scale2);
+      cur = nxt;
+      rows_nxt[0] = rows_nn[0];
+      rows_nxt[1] = rows_nn[1];
+    }
   }
 
-  // ---- merge the 4 wavefronts of the workgroup
+  // ---- merge the NW wavefronts of the workgroup
   float l = st.l;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -225,13 +261,14 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_acc[wid][m * 4 + r][lane] = st.acc[m][r];
   __syncthreads();
+  if (wid >= 4) return;   // the first four wavefronts finish one accumulator register index each
 
   float M = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) M = fmaxf(M, s_m[w][c]);
-  float f[4], L = 0.f;
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][c]);
+  float f[NW], L = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const float mw = s_m[w][c];
     f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
     L += s_l[w][c] * f[w];
@@ -242,7 +279,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   for (int m = 0; m < NM; ++m) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += s_acc[w][m * 4 + wid][lane] * f[w];
+    for (int w = 0; w < NW; ++w) v += s_acc[w][m * 4 + wid][lane] * f[w];
     o[m] = v;
   }
   if (c >= G) return;
@@ -395,11 +432,23 @@ __global__ __launch_bounds__(256) void prefill_kernel(
 }
 
 // ------------------------------------------------------------------ C ABI
+// Wavefronts per workgroup: as many as fit the register file (D=128 holds two chunks of K/V in ~200 VGPRs).
+static int decode_waves(int D) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("NV_ATTN_WAVES");   // tuning aid
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 4 || forced == 8 || forced == 16) return (D == 128 && forced == 16) ? 8 : forced;
+  return D == 128 ? 8 : 8;
+}
+
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
   if (B <= 0 || Hkv <= 0) return 1;
-  int64_t groups = (int64_t)B * Hkv;
-  int splits = (int)((1024 + groups - 1) / groups);          // aim at >= 1024 workgroups of 4 wavefronts
-  int by_len = (max_context + 127) / 128;                     // at least one 32-token chunk per wavefront
+  const int64_t groups = (int64_t)B * Hkv;
+  // one workgroup of 8 wavefronts per CU already fills the machine: split only while there are fewer groups than CUs
+  int splits = (int)((256 + groups - 1) / groups);
+  int by_len = (max_context + 255) / 256;                     // at least one 32-token chunk per wavefront
   if (splits > by_len) splits = by_len;
   if (splits > 32) splits = 32;
   if (splits < 1) splits = 1;
@@ -434,14 +483,22 @@ extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const v
   float* part_ml = part_o ? part_o + (size_t)B * H * num_splits * D : nullptr;
   const float scale2 = scale * LOG2E;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(num_splits, Hkv, B), block(256);
-#define LAUNCH_DEC(TT, DD)                                                                                           \
-  paged_decode_kernel<TT, DD><<<grid, block, 0, s>>>((const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache,    \
-                                                     (const uint16_t*)v_cache, block_tables, bt_stride, context_lens, \
-                                                     (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv,        \
-                                                     block_size, scale2, num_splits)
-  if (dtype == NV_BF16) { if (D == 128) LAUNCH_DEC(bf16_t, 128); else LAUNCH_DEC(bf16_t, 64); }
-  else                  { if (D == 128) LAUNCH_DEC(f16_t, 128); else LAUNCH_DEC(f16_t, 64); }
+  dim3 block(256);
+  const int nw = decode_waves(D);
+  dim3 grid(num_splits, Hkv, B);
+#define LAUNCH_DEC(TT, DD, WW)                                                                                       \
+  paged_decode_kernel<TT, DD, WW><<<grid, dim3(WW * 64), 0, s>>>(                                                    \
+      (const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, bt_stride, \
+      context_lens, (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv, block_size, scale2, num_splits)
+#define LAUNCH_DEC_T(TT)                                                         \
+  do {                                                                           \
+    if (D == 128) { if (nw == 4) LAUNCH_DEC(TT, 128, 4); else LAUNCH_DEC(TT, 128, 8); } \
+    else if (nw == 4) LAUNCH_DEC(TT, 64, 4);                                     \
+    else if (nw == 8) LAUNCH_DEC(TT, 64, 8);                                     \
+    else LAUNCH_DEC(TT, 64, 16);                                                 \
+  } while (0)
+  if (dtype == NV_BF16) LAUNCH_DEC_T(bf16_t); else LAUNCH_DEC_T(f16_t);
+#undef LAUNCH_DEC_T
 #undef LAUNCH_DEC
   NV_CHECK_LAUNCH();
   if (num_splits > 1) {

@@ -76,11 +76,108 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const u
   }
 }
 
+// One workgroup per row, the row held in registers between the reduction and the scaling: used for the
+// model's hidden-size rows (few rows, each a few KB, possibly still spread over split-K slabs).
+template <typename T, bool ADD, bool PARTIAL, int NT, int NV>
+__global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, const uint16_t* res,
+                                                         const uint16_t* __restrict__ w, uint16_t* out,
+                                                         uint16_t* res_out, int64_t rows, int hidden, int64_t x_stride,
+                                                         int64_t out_stride, float eps, const float* __restrict__ part,
+                                                         int nparts) {
+  __shared__ float s_part[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden >> 3;
+  const int64_t slab = rows * hidden;
+  float v[NV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * NT;
+    if (i < nvec) {
+      u32x4 a;
+      if (PARTIAL) a = sum_partials<T>(part, slab, nparts, row * hidden + 8 * i);
+      else a = reinterpret_cast<const u32x4*>(x + row * x_stride)[i];
+      u32x4 b = {0, 0, 0, 0};
+      if (ADD) b = reinterpret_cast<const u32x4*>(res + row * x_stride)[i];
+      u32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = lo_f32<T>(a[j]), hi = hi_f32<T>(a[j]);
+        if (ADD) {
+          lo = lo + lo_f32<T>(b[j]);
+          hi = hi + hi_f32<T>(b[j]);
+          r[j] = pack2<T>(lo, hi);
+        }
+        v[k][2 * j] = lo;
+        v[k][2 * j + 1] = hi;
+        ss = fmaf(lo, lo, ss);
+        ss = fmaf(hi, hi, ss);
+      }
+      if (ADD) reinterpret_cast<u32x4*>(res_out + row * x_stride)[i] = r;
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) s_part[wid] = ss;
+  __syncthreads();
+  ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) ss += s_part[k];
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * NT;
+    if (i < nvec) {
+      const u32x4 ww = reinterpret_cast<const u32x4*>(w)[i];
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float nlo = bits_to_f32<T>(f32_to_bits<T>(v[k][2 * j] * inv));
+        const float nhi = bits_to_f32<T>(f32_to_bits<T>(v[k][2 * j + 1] * inv));
+        o[j] = pack2<T>(nlo * lo_f32<T>(ww[j]), nhi * hi_f32<T>(ww[j]));
+      }
+      reinterpret_cast<u32x4*>(out + row * out_stride)[i] = o;
+    }
+  }
+}
+
+template <typename T, bool ADD, bool PARTIAL>
+static bool launch_norm_row(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
+                            int hidden, int64_t xs, int64_t os, float eps, hipStream_t s, const float* part,
+                            int nparts) {
+  const int nvec = hidden >> 3;
+#define ROW_GO(NTV, NVV)                                                                                             \
+  rmsnorm_row_kernel<T, ADD, PARTIAL, NTV, NVV><<<dim3((unsigned)rows), dim3(NTV), 0, s>>>(                          \
+      (const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out, rows, hidden, \
+      xs, os, eps, part, nparts)
+  if (nvec <= 128) ROW_GO(128, 1);
+  else if (nvec <= 256) ROW_GO(256, 1);
+  else if (nvec <= 512) ROW_GO(256, 2);
+  else if (nvec <= 1024) ROW_GO(256, 4);
+  else return false;
+#undef ROW_GO
+  return true;
+}
+
 template <bool ADD, bool PARTIAL = false>
 static int launch_norm(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
                        int hidden, int64_t xs, int64_t os, float eps, int dtype, hipStream_t s,
                        const float* part = nullptr, int nparts = 0) {
   if (rows == 0) return NV_OK;
+  // few long rows: one workgroup per row; many short rows (per-head norms): one wavefront per row
+  if ((PARTIAL || hidden >= 512) && rows <= 0x7fffffff) {
+    const bool ok = (dtype == NV_BF16)
+        ? launch_norm_row<bf16_t, ADD, PARTIAL>(x, res, w, out, res_out, rows, hidden, xs, os, eps, s, part, nparts)
+        : launch_norm_row<f16_t, ADD, PARTIAL>(x, res, w, out, res_out, rows, hidden, xs, os, eps, s, part, nparts);
+    if (ok) {
+      NV_CHECK_LAUNCH();
+      return NV_OK;
+    }
+    if (PARTIAL) {
+      nv_set_error("nv_add_rmsnorm_splitk: hidden=%d above the 8192 this kernel covers", hidden);
+      return NV_ERR_UNSUPPORTED;
+    }
+  }
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == NV_BF16)
     rmsnorm_kernel<bf16_t, ADD, PARTIAL><<<grid, block, 0, s>>>((const uint16_t*)x, (const uint16_t*)res,

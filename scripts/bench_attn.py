@@ -1,0 +1,48 @@
+"""Micro-benchmark of nv_paged_attn_decode: L layers' caches visited in turn inside one hipGraph (no L3 reuse)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from byox_vllm_amd import kernels
+
+def run(B, H, Hkv, D, S, L, splits_list, bs=256, dt=torch.bfloat16):
+    dev = "cuda"
+    nblk = B * (-(-S // bs))
+    kv = torch.randn(2, L, nblk, bs, Hkv, D, device=dev, dtype=dt)
+    q = torch.randn(B, H, D, device=dev, dtype=dt)
+    ctx = torch.full((B,), S, dtype=torch.int32, device=dev)
+    tables = torch.arange(nblk, dtype=torch.int32, device=dev).view(B, -1)
+    out = torch.empty_like(q)
+    bytes_per = B * S * 2 * Hkv * D * 2
+    for splits in splits_list:
+        for l in range(L):
+            kernels.paged_attn_decode(q, kv[0, l], kv[1, l], ctx, tables, D ** -0.5, out=out, num_splits=splits)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for l in range(L):
+                kernels.paged_attn_decode(q, kv[0, l], kv[1, l], ctx, tables, D ** -0.5, out=out, num_splits=splits)
+        g.replay(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        a.record()
+        for _ in range(reps):
+            g.replay()
+        b.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / (reps * L)
+        print(f"B={B} H={H}/{Hkv} D={D} S={S} waves={os.environ.get('NV_ATTN_WAVES','auto')} splits={splits}: "
+              f"{us:7.2f} us/launch  {bytes_per / us / 1e6:6.2f} TB/s", flush=True)
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "0.5b"
+    if which == "0.5b":
+        run(128, 14, 2, 64, 1024, 24, [1, 2, 4])
+    elif which == "7b":
+        run(128, 28, 4, 128, 1024, 8, [1, 2])
+    elif which == "small":
+        run(32, 14, 2, 64, 1024, 24, [1, 2, 4, 8])
+        run(1, 14, 2, 64, 1024, 24, [1, 4, 8, 16])
+    elif which == "layout":
+        run(128, 14, 2, 64, 1024, 24, [1])      # rows of the two kv heads interleaved (reference layout)
+        run(256, 7, 1, 64, 1024, 24, [1])       # same bytes, every stream contiguous
+        run(128, 14, 2, 64, 4096, 6, [1])       # longer context: prologue/epilogue amortised
+        run(256, 7, 1, 64, 4096, 6, [1])
