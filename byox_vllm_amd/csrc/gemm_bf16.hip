@@ -1,0 +1,5 @@
+// bf16 instantiations of the decode GEMM.
+#include "gemm_impl.h"
+
+void nv_gemm_launch_bf16(const GemmArgs& a) { gemm_dispatch<bf16_t>(a); }
+void nv_gemm_reduce_bf16(const GemmArgs& a) { reduce_dispatch<bf16_t>(a); }

@@ -1,0 +1,5 @@
+// fp16 instantiations of the decode GEMM.
+#include "gemm_impl.h"
+
+void nv_gemm_launch_f16(const GemmArgs& a) { gemm_dispatch<f16_t>(a); }
+void nv_gemm_reduce_f16(const GemmArgs& a) { reduce_dispatch<f16_t>(a); }

@@ -1,0 +1,350 @@
+// Templates of the decode GEMM (see gemm.hip for the design notes); instantiated per dtype in gemm_bf16.hip / gemm_f16.hip.
+#pragma once
+#include "common.h"
+
+#define GEMM_BK 128
+
+// 8 weights of one lane's fragment -> model dtype, from 8 int4 nibbles (one dword).
+// Two masks spread the nibbles into bytes (even elements / odd elements), v_cvt_f32_ubyteN turns each byte into
+// an exact float u, and fma(u, s, -8 s) is the correctly rounded fp32 product (u - 8) * s that the CPU dequantiser
+// forms (8 s is exact), rounded once more to the model dtype.
+template <typename T>
+__device__ __forceinline__ typename VecOf<T>::x8 dequant_w4(uint32_t q, float s, float neg8s) {
+  typename VecOf<T>::x8 f;
+  uint32_t even = q & 0x0f0f0f0fu, odd = (q >> 4) & 0x0f0f0f0fu;
+  // hide the masks from the optimiser, or it narrows the byte extracts below to 4-bit field extracts and
+  // misses the single-instruction byte-to-float conversions
+  asm volatile("" : "+v"(even), "+v"(odd));
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    f[2 * b] = (T)fmaf((float)((even >> (8 * b)) & 0xffu), s, neg8s);
+    f[2 * b + 1] = (T)fmaf((float)((odd >> (8 * b)) & 0xffu), s, neg8s);
+  }
+  return f;
+}
+
+// 8 int8 weights (two dwords) -> model dtype: value = q * s.
+template <typename T>
+__device__ __forceinline__ typename VecOf<T>::x8 dequant_w8(uint32_t lo, uint32_t hi, float s) {
+  typename VecOf<T>::x8 f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[e] = (T)((float)(int8_t)(lo >> (8 * e)) * s);
+    f[4 + e] = (T)((float)(int8_t)(hi >> (8 * e)) * s);
+  }
+  return f;
+}
+
+
+// NTW = 16-column tiles per wavefront (a workgroup covers 64*NTW columns): the x fragment read from LDS is reused
+// for NTW MFMAs, which divides the LDS read traffic and the x re-reads from L2 by NTW.
+// A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
+// two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
+// dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
+template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split
+__global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+                                                   const void* __restrict__ w, const uint16_t* __restrict__ scales,
+                                                   const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                   int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
+                                                   int K, int split_k) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int TM = BM / 16;                       // 16-row tiles of x per workgroup
+  constexpr int XCH = BM * 16;                      // 16-byte chunks in one x tile
+  constexpr int XV = (XCH + 511) / 512;             // chunks per thread
+  constexpr int RED_REGS = (NTW * TM + 1) / 2;      // accumulator tiles exchanged per reduction pass
+  constexpr int LDS_X = 2 * BM * GEMM_BK * 2, LDS_RED = RED_REGS * 256 * 16;
+  constexpr int LDS_BYTES = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES];
+  uint16_t (*lds_x)[BM * GEMM_BK] = reinterpret_cast<uint16_t (*)[BM * GEMM_BK]>(lds_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = wave & 3, kg = wave >> 2;         // column group of 4 wavefronts, k-step group
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int nkb_total = K / GEMM_BK;
+  const int per = (nkb_total + split_k - 1) / split_k;   // K-blocks of this split: contiguous range
+  const int kb_begin = blockIdx.z * per;
+  int kb_end = kb_begin + per;
+  if (kb_end > nkb_total) kb_end = nkb_total;
+  const int ntiles = N >> 4;
+  const int nt0 = (blockIdx.x * 4 + wid) * NTW;          // this wavefront's first 16-column tile
+
+  f32x4 acc[NTW][TM];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging helpers ------------------------------------------------------
+  u32x4 xr[XV];
+  auto load_x = [&](int kb) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int chunk = tid + 512 * v;     // row = chunk / 16, 16-byte column = chunk % 16
+      const int row = chunk >> 4, col = chunk & 15;
+      const int64_t m = m0 + row;
+      if (chunk < XCH && m < M)
+        xr[v] = *reinterpret_cast<const u32x4*>(x + m * x_stride + (int64_t)kb * GEMM_BK + col * 8);
+      else
+        xr[v] = u32x4{0, 0, 0, 0};
+    }
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int chunk = tid + 512 * v;
+      const int row = chunk >> 4, col = chunk & 15;
+      if (chunk < XCH)
+        *reinterpret_cast<u32x4*>(&lds_x[buf][row * GEMM_BK + ((col ^ (row & 15)) << 3)]) = xr[v];
+    }
+  };
+  // raw weights of this wavefront's two k-steps of one K-block per tile (current and prefetched), and group scales
+  constexpr int WREG = (WFMT == NV_W_DENSE) ? 8 : (WFMT == NV_W_INT8 ? 4 : 2);
+  uint32_t wr[NTW][WREG], wn[NTW][WREG];
+  uint16_t sc[NTW], sn[NTW];
+  auto load_w = [&](int kb, uint32_t (&dst)[NTW][WREG], uint16_t (&sdst)[NTW]) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int nt = nt0 + j;
+      if (nt >= ntiles) {
+#pragma unroll
+        for (int e = 0; e < WREG; ++e) dst[j][e] = 0u;
+        sdst[j] = 0;
+        continue;
+      }
+      if constexpr (WFMT == NV_W_DENSE) {
+        const uint16_t* wp = reinterpret_cast<const uint16_t*>(w) + (int64_t)(16 * nt + c) * K + (int64_t)kb * GEMM_BK +
+                             64 * kg + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 32 * ks);
+          dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
+        }
+      } else if constexpr (WFMT == NV_W_INT8) {   // tiled [N/16][K/128][64 lanes][8 dwords]: dwords 4 kg .. 4 kg + 3
+        const u32x4 a = reinterpret_cast<const u32x4*>(w)[(((int64_t)nt * nkb_total + kb) * 64 + lane) * 2 + kg];
+        dst[j][0] = a[0]; dst[j][1] = a[1]; dst[j][2] = a[2]; dst[j][3] = a[3];
+        sdst[j] = scales[(int64_t)kb * N + 16 * nt + c];
+      } else {                                    // tiled [N/16][K/128][64 lanes][4 dwords]: dwords 2 kg, 2 kg + 1
+        const u32x2 a = reinterpret_cast<const u32x2*>(w)[(((int64_t)nt * nkb_total + kb) * 64 + lane) * 2 + kg];
+        dst[j][0] = a[0]; dst[j][1] = a[1];
+        sdst[j] = scales[(int64_t)kb * N + 16 * nt + c];
+      }
+    }
+  };
+
+  if (kb_begin < kb_end) {
+    load_x(kb_begin);
+    load_w(kb_begin, wr, sc);
+    store_x(0);
+  }
+  __syncthreads();
+
+  for (int kb = kb_begin; kb < kb_end; ++kb) {
+    const int buf = (kb - kb_begin) & 1;
+    const bool more = kb + 1 < kb_end;
+    if (more) {
+      load_x(kb + 1);
+      load_w(kb + 1, wn, sn);
+    }
+    float s[NTW], neg136s[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      s[j] = bits_to_f32<T>(sc[j]);
+      neg136s[j] = -8.0f * s[j];
+    }
+#pragma unroll
+    for (int kl = 0; kl < 2; ++kl) {
+      const int ks = 2 * kg + kl;
+      // all x fragments of this k-step first: their LDS latency is covered by the dequantisation below
+      frag_t xf[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = 16 * i + c;
+        xf[i] = *reinterpret_cast<const frag_t*>(&lds_x[buf][row * GEMM_BK + (((4 * ks + g) ^ c) << 3)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the VALU work that hides their latency
+      frag_t wf[NTW];   // dequantised just in time: one k-step of every tile
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        if constexpr (WFMT == NV_W_DENSE)
+          wf[j] = __builtin_bit_cast(frag_t, u32x4{wr[j][4 * kl], wr[j][4 * kl + 1], wr[j][4 * kl + 2], wr[j][4 * kl + 3]});
+        else if constexpr (WFMT == NV_W_INT8)
+          wf[j] = dequant_w8<T>(wr[j][2 * kl], wr[j][2 * kl + 1], s[j]);
+        else
+          wf[j] = dequant_w4<T>(wr[j][kl], s[j], neg136s[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[j][i] = mfma16(wf[j], xf[i], acc[j][i]);   // D[n][m]: lane (c, g) reg r = out[m = 16 i + c][n = 4 g + r]
+    }
+    if (more) {
+      store_x(buf ^ 1);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+        for (int e = 0; e < WREG; ++e) wr[j][e] = wn[j][e];
+        sc[j] = sn[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- add the second k-step group's accumulators into the first's, through LDS (two passes)
+  {
+    f32x4* red = reinterpret_cast<f32x4*>(lds_raw);   // [RED_REGS][256 threads of the column group]
+    const int t4 = tid & 255;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (kg == 1) {
+#pragma unroll
+        for (int r = 0; r < RED_REGS; ++r) {
+          const int idx = pass * RED_REGS + r;
+          if (idx < NTW * TM) red[r * 256 + t4] = acc[idx / TM][idx % TM];
+        }
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int r = 0; r < RED_REGS; ++r) {
+          const int idx = pass * RED_REGS + r;
+          if (idx < NTW * TM) acc[idx / TM][idx % TM] += red[r * 256 + t4];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (kg == 1) return;
+
+  // ---- epilogue: per tile, lane holds columns 16 nt + 4g .. +3 of rows m0 + 16 i + c
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int nt = nt0 + j;
+    if (nt >= ntiles) continue;
+    const int nb = 16 * nt + 4 * g;
+    if constexpr (EPI == 0) {
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(bias + nb);
+        b4[0] = lo_f32<T>(t[0]); b4[1] = hi_f32<T>(t[0]); b4[2] = lo_f32<T>(t[1]); b4[3] = hi_f32<T>(t[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + 16 * i + c;
+        if (m < M) {
+          u32x2 o;
+          o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
+          o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
+          *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+        }
+      }
+    } else if constexpr (EPI == 1) {
+      // rows of W were interleaved so that a lane's 4 columns are (gate j, gate j+1, up j, up j+1):
+      // out[m][j] = dtype(dtype(silu(dtype(gate))) * dtype(up)), the roundings eager PyTorch performs
+      const int j0 = 8 * nt + 2 * g;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + 16 * i + c;
+        if (m < M) {
+          float r[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float gt = bits_to_f32<T>(f32_to_bits<T>(acc[j][i][e]));
+            const float up = bits_to_f32<T>(f32_to_bits<T>(acc[j][i][2 + e]));
+            const float sl = bits_to_f32<T>(f32_to_bits<T>(gt / (1.0f + expf(-gt))));
+            r[e] = sl * up;
+          }
+          *reinterpret_cast<uint32_t*>(out + m * out_stride + j0) = pack2<T>(r[0], r[1]);
+        }
+      }
+    } else {
+      float* slab = partial + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t m = m0 + 16 * i + c;
+        if (m < M) *reinterpret_cast<f32x4*>(slab + m * N + nb) = acc[j][i];
+      }
+    }
+  }
+}
+
+// Sum the split-K slabs in slab order, add the bias, round to the model dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
+                                                            const uint16_t* __restrict__ bias,
+                                                            uint16_t* __restrict__ out, int64_t out_stride, int64_t M,
+                                                            int N, int split_k) {
+  const int nvec = N >> 2;
+  const int64_t total = M * nvec;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = v / nvec;
+    const int n = (int)(v - m * nvec) << 2;
+    f32x4 s = *reinterpret_cast<const f32x4*>(partial + m * N + n);
+    for (int z = 1; z < split_k; ++z) s += *reinterpret_cast<const f32x4*>(partial + ((int64_t)z * M + m) * N + n);
+    if (bias) {
+      const u32x2 t = *reinterpret_cast<const u32x2*>(bias + n);
+      s[0] += lo_f32<T>(t[0]); s[1] += hi_f32<T>(t[0]); s[2] += lo_f32<T>(t[1]); s[3] += hi_f32<T>(t[1]);
+    }
+    u32x2 o;
+    o[0] = pack2<T>(s[0], s[1]);
+    o[1] = pack2<T>(s[2], s[3]);
+    *reinterpret_cast<u32x2*>(out + m * out_stride + n) = o;
+  }
+}
+
+
+#ifndef NV_GEMM_ARGS
+#define NV_GEMM_ARGS
+struct GemmArgs {
+  const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
+  float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
+};
+#endif
+
+template <typename T, int WFMT, int NTW, int EPI>
+static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
+#define GO(BMV)                                                                                               \
+  gemm_kernel<T, WFMT, BMV, NTW, EPI><<<grid, dim3(512), 0, a.stream>>>(                                      \
+      (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,  \
+      a.os, a.partial, a.M, a.N, a.K, a.split_k)
+  switch (a.bm) {
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    case 64: GO(64); break;
+    default: GO(128); break;
+  }
+#undef GO
+}
+
+template <typename T, int WFMT, int NTW>
+static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
+  if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
+  else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
+  else gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
+}
+
+// One dtype's instantiations: dense takes 1 or 2 tiles per wavefront (16 raw registers per tile), quantised 1 or 3.
+template <typename T>
+static void gemm_dispatch(const GemmArgs& a) {
+  const int ntiles = a.N / 16;
+  const int per_block = 4 * a.ntw;
+  dim3 grid((ntiles + per_block - 1) / per_block, (unsigned)((a.M + a.bm - 1) / a.bm), a.split_k);
+  if (a.wfmt == NV_W_DENSE) {
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2>(a, grid);
+  } else if (a.wfmt == NV_W_INT8) {
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1>(a, grid); else gemm_go_epi<T, NV_W_INT8, 3>(a, grid);
+  } else {
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT4, 1>(a, grid); else gemm_go_epi<T, NV_W_INT4, 3>(a, grid);
+  }
+}
+
+template <typename T>
+static void reduce_dispatch(const GemmArgs& a) {
+  const int64_t total = a.M * (a.N / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  splitk_reduce_kernel<T><<<dim3((unsigned)blocks), dim3(256), 0, a.stream>>>(
+      a.partial, (const uint16_t*)a.bias, (uint16_t*)a.out, a.os, a.M, a.N, a.split_k);
+}
