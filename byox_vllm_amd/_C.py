@@ -37,7 +37,8 @@ _PROTOS = {
     "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),
     "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "nv_sample_workspace_bytes": (_sz, [_i]),
-    "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _i, _p]),
+    "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _p, _i, _p]),
+    "nv_stage_decode_packed": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "nv_stage_decode_inputs": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

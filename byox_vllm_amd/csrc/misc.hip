@@ -134,10 +134,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void sample_partial_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
                                                              const float* __restrict__ temps,
                                                              const float* __restrict__ noise, float* __restrict__ pv,
-                                                             int* __restrict__ pi, int V, uint64_t seed) {
+                                                             int* __restrict__ pi, int V, uint64_t seed,
+                                                             const uint64_t* __restrict__ seed_offset) {
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (seed_offset) seed += seed_offset[0] * 0x9e3779b97f4a7c15ull;   // per-replay stream inside a captured graph
   const uint16_t* row = logits + (int64_t)b * row_stride;
   const float temp = temps[b];
   const bool greedy = temp == 0.0f;
@@ -195,7 +197,7 @@ extern "C" size_t nv_sample_workspace_bytes(int B) { return (size_t)B * SAMPLE_S
 
 extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
                          int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
-                         int dtype, nv_stream_t stream) {
+                         const uint64_t* seed_offset, int dtype, nv_stream_t stream) {
   NV_CHECK_ARG(logits && temperatures && tokens, "nv_sample: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_sample: bad dtype %d", dtype);
   NV_CHECK_ARG(V > 0 && B >= 0 && B <= 65535, "nv_sample: bad shape B=%d V=%d", B, V);
@@ -208,10 +210,10 @@ extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const fl
   dim3 grid(SAMPLE_SPLITS, B);
   if (dtype == NV_BF16)
     sample_partial_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
-                                                             noise, pv, pi, V, seed);
+                                                             noise, pv, pi, V, seed, seed_offset);
   else
     sample_partial_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
-                                                            noise, pv, pi, V, seed);
+                                                            noise, pv, pi, V, seed, seed_offset);
   NV_CHECK_LAUNCH();
   sample_final_kernel<<<dim3((B + 3) / 4), dim3(256), 0, s>>>(pv, pi, tokens, B);
   NV_CHECK_LAUNCH();
@@ -254,6 +256,48 @@ extern "C" int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positio
                                                                     bt_cols, g_ids, g_positions, g_slots,
                                                                     g_context_lens, g_block_tables, g_bt_cols, bs,
                                                                     padded_bs);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
+
+// Packed form of the staging above: ONE host->device copy carries the whole step
+// [ids | positions | slots | context_lens | temperature bits | block_tables], all as 32-bit words.
+__global__ __launch_bounds__(256) void stage_packed_kernel(const int32_t* __restrict__ p, int bs, int padded, int bt_cols,
+                                                           int64_t* g_ids, int64_t* g_pos, int32_t* g_slots,
+                                                           int32_t* g_ctx, int32_t* g_bt, int g_bt_cols, float* g_temps,
+                                                           uint64_t* step_counter) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  for (int i = tid; i < padded; i += nthr) {
+    const bool live = i < bs;
+    g_ids[i] = live ? p[i] : 0;
+    g_pos[i] = live ? p[bs + i] : 0;
+    g_slots[i] = live ? p[2 * bs + i] : -1;
+    g_ctx[i] = live ? p[3 * bs + i] : 0;
+    if (g_temps) g_temps[i] = live ? __int_as_float(p[4 * bs + i]) : 1.0f;
+  }
+  const int32_t* bt = p + 5 * bs;
+  for (int i = tid; i < bs * bt_cols; i += nthr) {
+    const int r = i / bt_cols, c = i - r * bt_cols;
+    g_bt[r * g_bt_cols + c] = bt[i];
+  }
+  if (tid == 0 && step_counter) step_counter[0] += 1;
+}
+
+extern "C" int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_cols, int64_t* g_ids,
+                                      int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
+                                      int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,
+                                      uint64_t* step_counter, nv_stream_t stream) {
+  NV_CHECK_ARG(packed && g_ids && g_positions && g_slots && g_context_lens && g_block_tables,
+               "nv_stage_decode_packed: null pointer");
+  NV_CHECK_ARG(bs >= 0 && padded_bs >= bs && bt_cols >= 0 && bt_cols <= g_bt_cols,
+               "nv_stage_decode_packed: bs=%d padded=%d bt_cols=%d g_bt_cols=%d", bs, padded_bs, bt_cols, g_bt_cols);
+  if (padded_bs == 0) return NV_OK;
+  int work = bs * bt_cols > padded_bs ? bs * bt_cols : padded_bs;
+  int blocks = (work + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  stage_packed_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
+      packed, bs, padded_bs, bt_cols, g_ids, g_positions, g_slots, g_context_lens, g_block_tables, g_bt_cols,
+      g_temperatures, step_counter);
   NV_CHECK_LAUNCH();
   return NV_OK;
 }

@@ -11,13 +11,14 @@ import torch
 from byox_vllm_amd import _C
 from byox_vllm_amd._C import check, dtype_code, lib, ptr, require_gpu, stream
 
-_workspaces: dict[tuple[int, str], torch.Tensor] = {}
+_workspaces: dict[tuple, torch.Tensor] = {}
 _retired: list[torch.Tensor] = []   # outgrown buffers stay alive: captured graphs may still point at them
 
 
 def workspace(nbytes: int, device, tag: str = "main") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag).  Size it before graph capture."""
-    key = (torch.device(device).index or 0, tag)
+    # one buffer per stream: micro-batches captured on parallel streams must not share scratch space
+    key = (torch.device(device).index or 0, tag, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
@@ -216,7 +217,7 @@ def embed(ids, weight, vocab_start=0, out=None):
     return out
 
 
-def sample(logits, temperatures, noise=None, seed=0, out=None):
+def sample(logits, temperatures, noise=None, seed=0, out=None, seed_offset=None):
     require_gpu(logits, "sample")
     B, V = logits.shape
     assert logits.stride(1) == 1 and temperatures.dtype == torch.float32 and temperatures.numel() == B
@@ -225,7 +226,8 @@ def sample(logits, temperatures, noise=None, seed=0, out=None):
     out = torch.empty(B, dtype=torch.int64, device=logits.device) if out is None else out
     ws = workspace(lib().nv_sample_workspace_bytes(B), logits.device, "sample")
     check(lib().nv_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(noise), ptr(out), ptr(ws), ws.numel(),
-                          B, V, seed & 0xFFFFFFFFFFFFFFFF, dtype_code(logits.dtype), stream()), "nv_sample")
+                          B, V, seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_offset), dtype_code(logits.dtype), stream()),
+          "nv_sample")
     return out
 
 
@@ -238,3 +240,11 @@ def stage_decode_inputs(ids, positions, slots, context_lens, block_tables, g):
                                        cols, ptr(g["input_ids"]), ptr(g["positions"]), ptr(g["slot_mapping"]),
                                        ptr(g["context_lens"]), ptr(g["block_tables"]), g["block_tables"].size(1),
                                        bs, padded, stream()), "nv_stage_decode_inputs")
+
+
+def stage_decode_packed(packed, bs, bt_cols, g):
+    """Unpack one step's host buffer (already copied to the device) into the static graph buffers ``g``."""
+    check(lib().nv_stage_decode_packed(ptr(packed), bs, g["padded_bs"], bt_cols, ptr(g["input_ids"]),
+                                       ptr(g["positions"]), ptr(g["slot_mapping"]), ptr(g["context_lens"]),
+                                       ptr(g["block_tables"]), g["block_tables"].size(1), ptr(g.get("temperatures")),
+                                       ptr(g.get("step")), stream()), "nv_stage_decode_packed")

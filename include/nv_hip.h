@@ -162,8 +162,10 @@ int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int h
  * to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V. */
 size_t nv_sample_workspace_bytes(int B);
 int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
-              int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed, int dtype,
-              nv_stream_t stream);
+              int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
+              const uint64_t* seed_offset /* device word mixed into the seed, or NULL: lets a captured
+                                             launch draw fresh noise on every replay */,
+              int dtype, nv_stream_t stream);
 
 /* Graph-replay staging — nanovllm/engine/model_runner.py:246-252 as ONE launch:
  * copies the step's ids/positions/slots/context_lens/block_tables into the
@@ -173,6 +175,15 @@ int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positions, const i
                            const int32_t* context_lens, const int32_t* block_tables, int bt_cols,
                            int64_t* g_ids, int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
                            int32_t* g_block_tables, int g_bt_cols, int bs, int padded_bs, nv_stream_t stream);
+
+/* The same staging fed by ONE packed host buffer of 32-bit words
+ * [ids(bs) | positions(bs) | slots(bs) | context_lens(bs) | temperatures as float bits(bs) | block_tables(bs*bt_cols)]
+ * (one host->device copy per step instead of the reference's five, model_runner.py:216-224,232);
+ * also fills g_temperatures (padding rows 1.0) and adds 1 to *step_counter when given. */
+int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_cols,
+                           int64_t* g_ids, int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
+                           int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,
+                           uint64_t* step_counter, nv_stream_t stream);
 
 #ifdef __cplusplus
 }
