@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnv_hip.so")
+# NV_HIP_LIB points at another build of the same library (A/B measurements); the default is the in-tree build.
+LIB_PATH = os.environ.get("NV_HIP_LIB") or os.path.join(_HERE, "libnv_hip.so")
 
 NV_BF16, NV_F16 = 0, 1
 W_DENSE, W_INT8, W_INT4 = 0, 1, 2

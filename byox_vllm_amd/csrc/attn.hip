@@ -221,30 +221,41 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
 
   const int n_chunks = (n_keys + 31) >> 5;
   const int step = splits * NW;
-  // rows of a chunk's two tiles; a tile that starts past the end re-reads the chunk's first tile (masked anyway)
+  const int max_blk = bt_stride - 1;
+  // Rows of a chunk's two tiles; a tile that starts past the end re-reads the chunk's first tile (masked anyway).
+  // Chunks are dealt round-robin, so at any moment the wavefronts of a workgroup stream one contiguous region of
+  // the cache.  The block-table reads of the first chunk do not wait for the context length: the index is clamped
+  // to the table's width and the rows are only used once the chunk is known to exist.
   auto lookup = [&](int ch, int64_t (&rows)[2]) {
-    const int base = ch << 5;
-    rows[0] = paged_tile_row(bt_row, base, block_size);
-    rows[1] = (base + 16 < n_keys) ? paged_tile_row(bt_row, base + 16, block_size) : rows[0];
+    const int tok0 = ch << 5, tok1 = tok0 + 16;
+    int b0 = tok0 / block_size, b1 = tok1 / block_size;
+    b0 = b0 > max_blk ? max_blk : b0;
+    b1 = b1 > max_blk ? max_blk : b1;
+    const int64_t r0 = (int64_t)bt_row[b0] * block_size + (tok0 - b0 * block_size);
+    const int64_t r1 = (int64_t)bt_row[b1] * block_size + (tok1 - b1 * block_size);
+    rows[0] = r0;
+    rows[1] = tok1 < n_keys ? r1 : r0;
   };
   int ch = split * NW + wid;
-  if (ch < n_chunks) {
+  {
     int64_t rows_cur[2], rows_nxt[2] = {0, 0};
     lookup(ch, rows_cur);
-    if (ch + step < n_chunks) lookup(ch + step, rows_nxt);
-    ChunkRegs<T, D> cur, nxt;
-    chunk_load<T, D, false>(cur, k_base, v_base, row_stride, rows_cur, INT64_MAX);
-    for (; ch < n_chunks; ch += step) {
-      const bool has_next = ch + step < n_chunks;
-      int64_t rows_nn[2] = {0, 0};
-      if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
-      if (has_next) chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
-      const int base = ch << 5;
-      if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, cur, qf, base, n_keys, n_keys, scale2);
-      else chunk_compute<T, D, true>(st, cur, qf, base, n_keys, n_keys, scale2);
-      cur = nxt;
-      rows_nxt[0] = rows_nn[0];
-      rows_nxt[1] = rows_nn[1];
+    if (ch < n_chunks) {
+      if (ch + step < n_chunks) lookup(ch + step, rows_nxt);
+      ChunkRegs<T, D> cur, nxt;
+      chunk_load<T, D, false>(cur, k_base, v_base, row_stride, rows_cur, INT64_MAX);
+      for (; ch < n_chunks; ch += step) {
+        const bool has_next = ch + step < n_chunks;
+        int64_t rows_nn[2] = {0, 0};
+        if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
+        if (has_next) chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
+        const int base = ch << 5;
+        if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, cur, qf, base, n_keys, n_keys, scale2);
+        else chunk_compute<T, D, true>(st, cur, qf, base, n_keys, n_keys, scale2);
+        cur = nxt;
+        rows_nxt[0] = rows_nn[0];
+        rows_nxt[1] = rows_nn[1];
+      }
     }
   }
 
@@ -475,6 +486,7 @@ extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const v
                "nv_paged_attn_decode: pointers must be 16-byte aligned");
   NV_CHECK_ARG(B >= 0 && B <= 65535 && Hkv <= 65535, "nv_paged_attn_decode: B=%d too large for one launch", B);
   if (B == 0) return NV_OK;
+  NV_CHECK_ARG(bt_stride >= 1, "nv_paged_attn_decode: block table row stride %d < 1", bt_stride);
   if (num_splits <= 0) num_splits = 1;
   const size_t need = nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits);
   NV_CHECK_ARG(need == 0 || (workspace && workspace_bytes >= need),

@@ -1,14 +1,50 @@
 // RoPE (+ optional per-head RMSNorm) on q/k in place, fused with the KV-cache
 // store, and the stand-alone KV-cache store.
 //
-// One wavefront per (token, head-slot).  Head-slots 0..H-1 are q heads,
+// Work items are (token, head-slot) pairs.  Head-slots 0..H-1 are q heads,
 // H..H+Hkv-1 are k heads (rotated in place and copied to the cache row of the
-// token's slot), H+Hkv..H+2Hkv-1 are v heads (copied only).  A lane owns the
-// pair (x[i], x[i + D/2]) for i = lane, lane+64... so the rotation needs no
-// cross-lane traffic; the per-head norm is one wave reduction.
+// token's slot), H+Hkv..H+2Hkv-1 are v heads (copied only).  D/8 lanes share a
+// head: a lane owns elements [4i, 4i+4) of the first half and the matching four
+// of the second half, so the rotation needs no cross-lane traffic, every access
+// is 8 or 16 bytes wide, and the per-head norm is a reduction over D/8 lanes.
 #include "common.h"
 
-template <typename T, bool PARTIAL>
+#define ROPE_MAX_UNROLLED_SLABS 8
+
+// Four consecutive columns of a row that exists only as split-K slabs: slabs summed in order, plus bias.
+// The loads of up to 8 slabs are issued together; the adds then run in slab order (deterministic).
+template <typename T, int NP>
+__device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ p, int64_t slab) {
+  f32x4 v[NP];
+#pragma unroll
+  for (int z = 0; z < NP; ++z) v[z] = *reinterpret_cast<const f32x4*>(p + z * slab);
+  f32x4 a = v[0];
+#pragma unroll
+  for (int z = 1; z < NP; ++z) a += v[z];
+  return a;
+}
+
+__device__ __forceinline__ f32x4 slab_sum4_any(const float* __restrict__ p, int64_t slab, int nparts) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  for (int z = 1; z < nparts; ++z) a += *reinterpret_cast<const f32x4*>(p + z * slab);
+  return a;
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4 unpack4(u32x2 w) {
+  return f32x4{lo_f32<T>(w[0]), hi_f32<T>(w[0]), lo_f32<T>(w[1]), hi_f32<T>(w[1])};
+}
+template <typename T>
+__device__ __forceinline__ u32x2 pack4(f32x4 v) {
+  return u32x2{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+}
+// round to the model dtype and back
+template <typename T>
+__device__ __forceinline__ f32x4 round4(f32x4 v) {
+  return unpack4<T>(pack4<T>(v));
+}
+
+template <typename T, int NP>  // NP: number of split-K slabs (0 = the qkv rows already exist, -1 = run-time count)
 __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride,
                                                       const int64_t* __restrict__ positions,
                                                       const float* __restrict__ cos_sin,
@@ -17,72 +53,88 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
                                                       const uint16_t* __restrict__ kn_w, float eps, int64_t ntok, int H,
                                                       int Hkv, int D, const float* __restrict__ part, int nparts,
                                                       const uint16_t* __restrict__ bias) {
-  const int lane = threadIdx.x & 63;
+  const int lph = D >> 3;  // lanes per head: 2, 4, 8 or 16
   const int heads = H + 2 * Hkv;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= ntok * heads) return;
-  const int64_t t = item / heads;
-  const int hs = (int)(item - t * heads);
-  uint16_t* row = qkv + t * row_stride + (int64_t)hs * D;
+  const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lph;
+  const int sub = threadIdx.x & (lph - 1);
+  const bool live = item < ntok * heads;
+  const int64_t t = live ? item / heads : 0;
+  const int hs = live ? (int)(item - t * heads) : 0;
   const int half = D >> 1;
+  const int c1 = 4 * sub, c2 = half + 4 * sub;  // this lane's columns inside the head
+  uint16_t* row = qkv + t * row_stride + (int64_t)hs * D;
   const bool is_q = hs < H, is_k = !is_q && hs < H + Hkv;
   const int slot = slots ? slots[t] : -1;
 
-  // PARTIAL: the qkv row does not exist yet; build this head from the GEMM's split-K slabs (+ bias),
-  // rounded to the model dtype exactly as the GEMM epilogue would have stored it.
-  const int ncols = heads * D;
-  auto from_partials = [&](int col) -> uint16_t {
-    float a = 0.f;
-    for (int z = 0; z < nparts; ++z) a += part[((int64_t)z * ntok + t) * ncols + col];
-    if (bias) a += bits_to_f32<T>(bias[col]);
-    return f32_to_bits<T>(a);
-  };
+  f32x4 x1, x2;
+  if (NP != 0) {
+    // the qkv row does not exist yet: build this head from the GEMM's split-K slabs (+ bias), rounded to the
+    // model dtype exactly as the GEMM epilogue would have stored it
+    const int ncols = heads * D;
+    const int64_t slab = ntok * ncols;
+    const float* p = part + t * ncols + hs * D;
+    if (NP > 0) {
+      x1 = slab_sum4<T, (NP > 0 ? NP : 1)>(p + c1, slab);
+      x2 = slab_sum4<T, (NP > 0 ? NP : 1)>(p + c2, slab);
+    } else {
+      x1 = slab_sum4_any(p + c1, slab, nparts);
+      x2 = slab_sum4_any(p + c2, slab, nparts);
+    }
+    if (bias) {
+      x1 += unpack4<T>(*reinterpret_cast<const u32x2*>(bias + hs * D + c1));
+      x2 += unpack4<T>(*reinterpret_cast<const u32x2*>(bias + hs * D + c2));
+    }
+    x1 = round4<T>(x1);
+    x2 = round4<T>(x2);
+  } else {
+    x1 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c1));
+    x2 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c2));
+  }
 
   if (!is_q && !is_k) {  // v head: copy to the cache (and materialise it in the qkv buffer)
-    uint16_t* dst = (v_cache && slot >= 0) ? v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D : nullptr;
-    for (int i = lane; i < D; i += 64) {
-      uint16_t val;
-      if (PARTIAL) {
-        val = from_partials(hs * D + i);
-        row[i] = val;
-      } else {
-        val = row[i];
-      }
-      if (dst) dst[i] = val;
+    if (!live) return;
+    const u32x2 w1 = pack4<T>(x1), w2 = pack4<T>(x2);
+    if (NP != 0) {
+      *reinterpret_cast<u32x2*>(row + c1) = w1;
+      *reinterpret_cast<u32x2*>(row + c2) = w2;
+    }
+    if (v_cache && slot >= 0) {
+      uint16_t* dst = v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D;
+      *reinterpret_cast<u32x2*>(dst + c1) = w1;
+      *reinterpret_cast<u32x2*>(dst + c2) = w2;
     }
     return;
   }
 
   const uint16_t* nw = is_q ? qn_w : kn_w;
-  const float* cs = cos_sin + positions[t] * D;
-  // D <= 128: one (x1, x2) pair per lane (lanes >= D/2 idle for D = 64)
-  const bool act = lane < half;
-  float x1 = 0.f, x2 = 0.f;
-  if (act) {
-    x1 = bits_to_f32<T>(PARTIAL ? from_partials(hs * D + lane) : row[lane]);
-    x2 = bits_to_f32<T>(PARTIAL ? from_partials(hs * D + lane + half) : row[lane + half]);
-  }
   if (nw) {  // per-head RMSNorm (Qwen3): fp32 normalise, round, scale by weight in the model dtype
-    float ss = wave_sum(x1 * x1 + x2 * x2);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss += x1[j] * x1[j] + x2[j] * x2[j];
+    for (int o = lph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float inv = 1.0f / sqrtf(ss / (float)D + eps);
-    if (act) {
-      x1 = bits_to_f32<T>(f32_to_bits<T>(bits_to_f32<T>(f32_to_bits<T>(x1 * inv)) * bits_to_f32<T>(nw[lane])));
-      x2 = bits_to_f32<T>(f32_to_bits<T>(bits_to_f32<T>(f32_to_bits<T>(x2 * inv)) * bits_to_f32<T>(nw[lane + half])));
-    }
+    const f32x4 w1 = unpack4<T>(*reinterpret_cast<const u32x2*>(nw + c1));
+    const f32x4 w2 = unpack4<T>(*reinterpret_cast<const u32x2*>(nw + c2));
+    x1 = round4<T>(round4<T>(x1 * inv) * w1);
+    x2 = round4<T>(round4<T>(x2 * inv) * w2);
   }
-  if (act) {
-    const float c = cs[lane], s = cs[half + lane];
+  if (!live) return;
+  const float* cs = cos_sin + positions[t] * D;
+  const f32x4 c = *reinterpret_cast<const f32x4*>(cs + c1), sn = *reinterpret_cast<const f32x4*>(cs + c2);
+  f32x4 y1, y2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
     // separate roundings for each product and the sum, as eager fp32 PyTorch does
-    const float y1 = __fsub_rn(__fmul_rn(x1, c), __fmul_rn(x2, s));
-    const float y2 = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, s));
-    const uint16_t b1 = f32_to_bits<T>(y1), b2 = f32_to_bits<T>(y2);
-    row[lane] = b1;
-    row[lane + half] = b2;
-    if (is_k && k_cache && slot >= 0) {
-      uint16_t* dst = k_cache + ((int64_t)slot * Hkv + (hs - H)) * D;
-      dst[lane] = b1;
-      dst[lane + half] = b2;
-    }
+    y1[j] = __fsub_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(x2[j], sn[j]));
+    y2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
+  }
+  const u32x2 w1 = pack4<T>(y1), w2 = pack4<T>(y2);
+  *reinterpret_cast<u32x2*>(row + c1) = w1;
+  *reinterpret_cast<u32x2*>(row + c2) = w2;
+  if (is_k && k_cache && slot >= 0) {
+    uint16_t* dst = k_cache + ((int64_t)slot * Hkv + (hs - H)) * D;
+    *reinterpret_cast<u32x2*>(dst + c1) = w1;
+    *reinterpret_cast<u32x2*>(dst + c2) = w2;
   }
 }
 
@@ -118,16 +170,35 @@ static int rope_launch(void* qkv, int64_t qkv_row_stride, const int64_t* positio
   NV_CHECK_ARG((q_norm_w == nullptr) == (k_norm_w == nullptr), "nv_rope_kv_store: q_norm_w and k_norm_w go together");
   NV_CHECK_ARG(qkv_row_stride >= (int64_t)(H + 2 * Hkv) * D, "nv_rope_kv_store: row stride smaller than a qkv row");
   if (T == 0) return NV_OK;
+  NV_CHECK_ARG(qkv_row_stride % 4 == 0 && (uintptr_t)qkv % 8 == 0 && (uintptr_t)cos_sin % 16 == 0,
+               "nv_rope_kv_store: qkv must be 8-byte aligned with a row stride that is a multiple of 4, cos_sin 16-byte aligned");
+  NV_CHECK_ARG(((uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)q_norm_w | (uintptr_t)k_norm_w | (uintptr_t)bias) % 8 == 0 &&
+               (uintptr_t)partials % 16 == 0, "nv_rope_kv_store: misaligned pointer");
   const int64_t items = T * (H + 2 * Hkv);
-  dim3 grid((unsigned)((items + 3) / 4)), block(256);
+  const int64_t lanes = items * (D / 8);
+  NV_CHECK_ARG((lanes + 255) / 256 <= 0x7fffffff, "nv_rope_kv_store: T=%lld too large for one launch", (long long)T);
+  dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define ROPE_GO(TT, PP)                                                                                               \
   rope_kv_kernel<TT, PP><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, positions, cos_sin, slot_mapping,    \
                                                 (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,   \
                                                 (const uint16_t*)k_norm_w, eps, T, H, Hkv, D, partials, num_partials, \
                                                 (const uint16_t*)bias)
-  if (dtype == NV_BF16) { if (partials) ROPE_GO(bf16_t, true); else ROPE_GO(bf16_t, false); }
-  else                  { if (partials) ROPE_GO(f16_t, true); else ROPE_GO(f16_t, false); }
+#define ROPE_GO_T(TT)                                     \
+  switch (partials ? num_partials : 0) {                  \
+    case 0: ROPE_GO(TT, 0); break;                        \
+    case 1: ROPE_GO(TT, 1); break;                        \
+    case 2: ROPE_GO(TT, 2); break;                        \
+    case 3: ROPE_GO(TT, 3); break;                        \
+    case 4: ROPE_GO(TT, 4); break;                        \
+    case 5: ROPE_GO(TT, 5); break;                        \
+    case 6: ROPE_GO(TT, 6); break;                        \
+    case 7: ROPE_GO(TT, 7); break;                        \
+    case 8: ROPE_GO(TT, 8); break;                        \
+    default: ROPE_GO(TT, -1); break;                      \
+  }
+  if (dtype == NV_BF16) { ROPE_GO_T(bf16_t) } else { ROPE_GO_T(f16_t) }
+#undef ROPE_GO_T
 #undef ROPE_GO
   NV_CHECK_LAUNCH();
   return NV_OK;

@@ -34,10 +34,11 @@ def run(B, H, Hkv, D, S, L, splits_list, bs=256, dt=torch.bfloat16):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "0.5b"
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     if which == "0.5b":
-        run(128, 14, 2, 64, 1024, 24, [1, 2, 4])
+        run(128, 14, 2, 64, S, 24, [1, 2, 4])
     elif which == "7b":
-        run(128, 28, 4, 128, 1024, 8, [1, 2])
+        run(128, 28, 4, 128, S, 8, [1, 2])
     elif which == "small":
         run(32, 14, 2, 64, 1024, 24, [1, 2, 4, 8])
         run(1, 14, 2, 64, 1024, 24, [1, 4, 8, 16])
