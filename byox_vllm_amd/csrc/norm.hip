@@ -3,47 +3,15 @@
 // step), an xor-shuffle reduction of the sum of squares, 16-byte stores.  The
 // rows are a few KB, so the second pass over the row is served by the CU's L1.
 #include "common.h"
+#include "splitk.h"
 
 // x as the GEMM would have written it: the split-K slabs summed in slab order, rounded to the model dtype.
-// Up to 8 slabs: all loads are issued before the first add, so the row costs one memory latency, not one per slab.
-template <typename T, int NP>
-__device__ __forceinline__ u32x4 sum_partials_n(const float* __restrict__ p, int64_t slab) {
-  f32x4 a[NP], b[NP];
-#pragma unroll
-  for (int z = 0; z < NP; ++z) {
-    a[z] = *reinterpret_cast<const f32x4*>(p + z * slab);
-    b[z] = *reinterpret_cast<const f32x4*>(p + z * slab + 4);
-  }
-  f32x4 sa = a[0], sb = b[0];
-#pragma unroll
-  for (int z = 1; z < NP; ++z) {
-    sa += a[z];
-    sb += b[z];
-  }
-  return u32x4{pack2<T>(sa[0], sa[1]), pack2<T>(sa[2], sa[3]), pack2<T>(sb[0], sb[1]), pack2<T>(sb[2], sb[3])};
-}
-
 template <typename T>
 __device__ __forceinline__ u32x4 sum_partials(const float* __restrict__ part, int64_t slab, int nparts, int64_t off) {
-  const float* p = part + off;
-  switch (nparts) {  // uniform over the launch
-    case 1: return sum_partials_n<T, 1>(p, slab);
-    case 2: return sum_partials_n<T, 2>(p, slab);
-    case 3: return sum_partials_n<T, 3>(p, slab);
-    case 4: return sum_partials_n<T, 4>(p, slab);
-    case 5: return sum_partials_n<T, 5>(p, slab);
-    case 6: return sum_partials_n<T, 6>(p, slab);
-    case 7: return sum_partials_n<T, 7>(p, slab);
-    case 8: return sum_partials_n<T, 8>(p, slab);
-    default: break;
-  }
-  f32x4 a = *reinterpret_cast<const f32x4*>(p);
-  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
-  for (int z = 1; z < nparts; ++z) {
-    a += *reinterpret_cast<const f32x4*>(p + z * slab);
-    b += *reinterpret_cast<const f32x4*>(p + z * slab + 4);
-  }
-  return u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
+  f32x4 acc[2];
+  slab_sum<2>(part + off, slab, nparts, acc);
+  return u32x4{pack2<T>(acc[0][0], acc[0][1]), pack2<T>(acc[0][2], acc[0][3]), pack2<T>(acc[1][0], acc[1][1]),
+               pack2<T>(acc[1][2], acc[1][3])};
 }
 
 template <typename T, bool ADD, bool PARTIAL>

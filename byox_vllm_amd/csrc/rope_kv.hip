@@ -9,26 +9,7 @@
 // is 8 or 16 bytes wide, and the per-head norm is a reduction over D/8 lanes.
 #include "common.h"
 
-#define ROPE_MAX_UNROLLED_SLABS 8
-
-// Four consecutive columns of a row that exists only as split-K slabs: slabs summed in order, plus bias.
-// The loads of up to 8 slabs are issued together; the adds then run in slab order (deterministic).
-template <typename T, int NP>
-__device__ __forceinline__ f32x4 slab_sum4(const float* __restrict__ p, int64_t slab) {
-  f32x4 v[NP];
-#pragma unroll
-  for (int z = 0; z < NP; ++z) v[z] = *reinterpret_cast<const f32x4*>(p + z * slab);
-  f32x4 a = v[0];
-#pragma unroll
-  for (int z = 1; z < NP; ++z) a += v[z];
-  return a;
-}
-
-__device__ __forceinline__ f32x4 slab_sum4_any(const float* __restrict__ p, int64_t slab, int nparts) {
-  f32x4 a = *reinterpret_cast<const f32x4*>(p);
-  for (int z = 1; z < nparts; ++z) a += *reinterpret_cast<const f32x4*>(p + z * slab);
-  return a;
-}
+#include "splitk.h"
 
 template <typename T>
 __device__ __forceinline__ f32x4 unpack4(u32x2 w) {
@@ -44,7 +25,7 @@ __device__ __forceinline__ f32x4 round4(f32x4 v) {
   return unpack4<T>(pack4<T>(v));
 }
 
-template <typename T, int NP>  // NP: number of split-K slabs (0 = the qkv rows already exist, -1 = run-time count)
+template <typename T, bool PARTIAL>  // PARTIAL: the qkv rows exist only as split-K slabs
 __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride,
                                                       const int64_t* __restrict__ positions,
                                                       const float* __restrict__ cos_sin,
@@ -67,19 +48,17 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
   const int slot = slots ? slots[t] : -1;
 
   f32x4 x1, x2;
-  if (NP != 0) {
+  if (PARTIAL) {
     // the qkv row does not exist yet: build this head from the GEMM's split-K slabs (+ bias), rounded to the
     // model dtype exactly as the GEMM epilogue would have stored it
     const int ncols = heads * D;
     const int64_t slab = ntok * ncols;
     const float* p = part + t * ncols + hs * D;
-    if (NP > 0) {
-      x1 = slab_sum4<T, (NP > 0 ? NP : 1)>(p + c1, slab);
-      x2 = slab_sum4<T, (NP > 0 ? NP : 1)>(p + c2, slab);
-    } else {
-      x1 = slab_sum4_any(p + c1, slab, nparts);
-      x2 = slab_sum4_any(p + c2, slab, nparts);
-    }
+    f32x4 a1[1], a2[1];
+    slab_sum<1>(p + c1, slab, nparts, a1);
+    slab_sum<1>(p + c2, slab, nparts, a2);
+    x1 = a1[0];
+    x2 = a2[0];
     if (bias) {
       x1 += unpack4<T>(*reinterpret_cast<const u32x2*>(bias + hs * D + c1));
       x2 += unpack4<T>(*reinterpret_cast<const u32x2*>(bias + hs * D + c2));
@@ -94,7 +73,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
   if (!is_q && !is_k) {  // v head: copy to the cache (and materialise it in the qkv buffer)
     if (!live) return;
     const u32x2 w1 = pack4<T>(x1), w2 = pack4<T>(x2);
-    if (NP != 0) {
+    if (PARTIAL) {
       *reinterpret_cast<u32x2*>(row + c1) = w1;
       *reinterpret_cast<u32x2*>(row + c2) = w2;
     }
@@ -184,21 +163,8 @@ static int rope_launch(void* qkv, int64_t qkv_row_stride, const int64_t* positio
                                                 (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,   \
                                                 (const uint16_t*)k_norm_w, eps, T, H, Hkv, D, partials, num_partials, \
                                                 (const uint16_t*)bias)
-#define ROPE_GO_T(TT)                                     \
-  switch (partials ? num_partials : 0) {                  \
-    case 0: ROPE_GO(TT, 0); break;                        \
-    case 1: ROPE_GO(TT, 1); break;                        \
-    case 2: ROPE_GO(TT, 2); break;                        \
-    case 3: ROPE_GO(TT, 3); break;                        \
-    case 4: ROPE_GO(TT, 4); break;                        \
-    case 5: ROPE_GO(TT, 5); break;                        \
-    case 6: ROPE_GO(TT, 6); break;                        \
-    case 7: ROPE_GO(TT, 7); break;                        \
-    case 8: ROPE_GO(TT, 8); break;                        \
-    default: ROPE_GO(TT, -1); break;                      \
-  }
-  if (dtype == NV_BF16) { ROPE_GO_T(bf16_t) } else { ROPE_GO_T(f16_t) }
-#undef ROPE_GO_T
+  if (dtype == NV_BF16) { if (partials) ROPE_GO(bf16_t, true); else ROPE_GO(bf16_t, false); }
+  else                  { if (partials) ROPE_GO(f16_t, true); else ROPE_GO(f16_t, false); }
 #undef ROPE_GO
   NV_CHECK_LAUNCH();
   return NV_OK;

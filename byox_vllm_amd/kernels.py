@@ -6,6 +6,8 @@ Outputs are allocated with torch.empty unless an ``out`` buffer is given, so
 every call is capturable in a hipGraph (torch.cuda.graph) once warmed up.
 """
 
+import os
+
 import torch
 
 from byox_vllm_amd import _C
@@ -168,9 +170,12 @@ def silu_mul(x, out=None):
     return out
 
 
+MAX_SPLIT_K = int(os.environ.get("NV_MAX_SPLIT_K", "64"))
+
+
 def pick_split_k(M, N, K, target_blocks=256):
     tiles = (N // 64) * ((M + 127) // 128)
-    return max(1, min(K // 128, target_blocks // max(tiles, 1)))
+    return max(1, min(K // 128, target_blocks // max(tiles, 1), MAX_SPLIT_K))
 
 
 def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=False):

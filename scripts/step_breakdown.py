@@ -20,31 +20,19 @@ drv = bench.StepDriver(r, seqs, nb)
 for _ in range(5):
     drv.step()
 torch.cuda.synchronize()
-acc = dict(prepare=0.0, stage_replay=0.0, head=0.0, sample=0.0, tolist=0.0, total=0.0)
+# wall time of a whole step versus the device time of the graph replay inside it
+replay = r._replay
+spans = []
+def timed_replay(bs):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); replay(bs); b.record()
+    spans.append((a, b))
+r._replay = timed_replay
 N = 30
+t0 = time.perf_counter()
 for _ in range(N):
-    t0 = time.perf_counter()
-    ids, pos = r._prepare_decode(seqs)
-    temps = r._prepare_sample(seqs)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    ctx = get_context()
-    g = r.graph_vars
-    g["padded_bs"] = batch
-    from byox_vllm_amd import kernels
-    with torch.inference_mode():
-        kernels.stage_decode_inputs(ids, pos, ctx.slot_mapping, ctx.context_lens, ctx.block_tables.contiguous(), g)
-        r.graphs[batch].replay()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        logits = r.model.compute_logits(g["outputs"][:batch])
-        torch.cuda.synchronize(); t3 = time.perf_counter()
-        toks = r.sampler(logits, temps)
-        torch.cuda.synchronize(); t4 = time.perf_counter()
-    tl = toks.tolist(); t5 = time.perf_counter()
-    reset_context()
-    for s, t in zip(seqs, tl):
-        s.append_token(t)
-        if len(s) % 256 == 1:
-            s.block_table.append(drv.next_block); drv.next_block += 1
-    acc["prepare"] += t1 - t0; acc["stage_replay"] += t2 - t1; acc["head"] += t3 - t2
-    acc["sample"] += t4 - t3; acc["tolist"] += t5 - t4; acc["total"] += t5 - t0
-print({k: round(v / N * 1e3, 3) for k, v in acc.items()}, "ms per step")
+    drv.step()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / N * 1e3
+gpu = sum(a.elapsed_time(b) for a, b in spans) / len(spans)
+print(f"wall {wall:.3f} ms/step, graph replay on device {gpu:.3f} ms, host + copies + sync {wall - gpu:.3f} ms")
