@@ -76,121 +76,216 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
     for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- staging helpers ------------------------------------------------------
+  // Loads are unconditional (rows past M re-read row M-1, tiles past N re-read the last tile; their results are
+  // never stored), so the K loop is straight-line code the scheduler can interleave.
+  // Addresses are a wave-uniform 64-bit part (scalar registers) plus a 32-bit per-lane byte offset computed once.
   u32x4 xr[XV];
+  uint32_t x_lane_off[XV];
+#pragma unroll
+  for (int v = 0; v < XV; ++v) {
+    const int chunk = (tid + 512 * v) & (XCH - 1);     // row = chunk / 16, 16-byte column = chunk % 16
+    const int row = chunk >> 4, col = chunk & 15;
+    int64_t m = m0 + row;
+    m = m < M ? m : M - 1;
+    x_lane_off[v] = (uint32_t)((m - m0) * x_stride * 2 + col * 16);
+  }
+  const char* x_base = reinterpret_cast<const char*>(x + m0 * x_stride);
+  auto load_x_chunk = [&](int kb, int v) {
+    xr[v] = *reinterpret_cast<const u32x4*>(x_base + (int64_t)kb * (GEMM_BK * 2) + x_lane_off[v]);
+  };
+  auto store_x_chunk = [&](int buf, int v) {
+    const int chunk = tid + 512 * v;
+    const int row = chunk >> 4, col = chunk & 15;
+    if (XCH % 512 == 0 || chunk < XCH)   // only the 16-row tile leaves threads without a chunk
+      *reinterpret_cast<u32x4*>(&lds_x[buf][row * GEMM_BK + ((col ^ (row & 15)) << 3)]) = xr[v];
+  };
   auto load_x = [&](int kb) {
 #pragma unroll
-    for (int v = 0; v < XV; ++v) {
-      const int chunk = tid + 512 * v;     // row = chunk / 16, 16-byte column = chunk % 16
-      const int row = chunk >> 4, col = chunk & 15;
-      const int64_t m = m0 + row;
-      if (chunk < XCH && m < M)
-        xr[v] = *reinterpret_cast<const u32x4*>(x + m * x_stride + (int64_t)kb * GEMM_BK + col * 8);
-      else
-        xr[v] = u32x4{0, 0, 0, 0};
-    }
+    for (int v = 0; v < XV; ++v) load_x_chunk(kb, v);
   };
   auto store_x = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < XV; ++v) {
-      const int chunk = tid + 512 * v;
-      const int row = chunk >> 4, col = chunk & 15;
-      if (chunk < XCH)
-        *reinterpret_cast<u32x4*>(&lds_x[buf][row * GEMM_BK + ((col ^ (row & 15)) << 3)]) = xr[v];
-    }
+    for (int v = 0; v < XV; ++v) store_x_chunk(buf, v);
   };
   // raw weights of this wavefront's two k-steps of one K-block per tile (current and prefetched), and group scales
   constexpr int WREG = (WFMT == NV_W_DENSE) ? 8 : (WFMT == NV_W_INT8 ? 4 : 2);
   uint32_t wr[NTW][WREG], wn[NTW][WREG];
   uint16_t sc[NTW], sn[NTW];
+  const uint32_t w_lane_off = (WFMT == NV_W_DENSE) ? (uint32_t)((c * K + 8 * g) * 2)
+                              : (WFMT == NV_W_INT8 ? (uint32_t)(lane * 32 + kg * 16) : (uint32_t)(lane * 16 + kg * 8));
+  const uint32_t s_lane_off = (uint32_t)(c * 2);
   auto load_w = [&](int kb, uint32_t (&dst)[NTW][WREG], uint16_t (&sdst)[NTW]) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      const int nt = nt0 + j;
-      if (nt >= ntiles) {
-#pragma unroll
-        for (int e = 0; e < WREG; ++e) dst[j][e] = 0u;
-        sdst[j] = 0;
-        continue;
-      }
+      const int nt = nt0 + j < ntiles ? nt0 + j : ntiles - 1;
+      const char* wb8 = reinterpret_cast<const char*>(w);
       if constexpr (WFMT == NV_W_DENSE) {
-        const uint16_t* wp = reinterpret_cast<const uint16_t*>(w) + (int64_t)(16 * nt + c) * K + (int64_t)kb * GEMM_BK +
-                             64 * kg + 8 * g;
+        const char* wp = wb8 + ((int64_t)16 * nt * K + (int64_t)kb * GEMM_BK + 64 * kg) * 2 + w_lane_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 32 * ks);
+          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 64 * ks);
           dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
         }
       } else if constexpr (WFMT == NV_W_INT8) {   // tiled [N/16][K/128][64 lanes][8 dwords]: dwords 4 kg .. 4 kg + 3
-        const u32x4 a = reinterpret_cast<const u32x4*>(w)[(((int64_t)nt * nkb_total + kb) * 64 + lane) * 2 + kg];
+        const u32x4 a = *reinterpret_cast<const u32x4*>(wb8 + ((int64_t)nt * nkb_total + kb) * 2048 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1]; dst[j][2] = a[2]; dst[j][3] = a[3];
-        sdst[j] = scales[(int64_t)kb * N + 16 * nt + c];
       } else {                                    // tiled [N/16][K/128][64 lanes][4 dwords]: dwords 2 kg, 2 kg + 1
-        const u32x2 a = reinterpret_cast<const u32x2*>(w)[(((int64_t)nt * nkb_total + kb) * 64 + lane) * 2 + kg];
+        const u32x2 a = *reinterpret_cast<const u32x2*>(wb8 + ((int64_t)nt * nkb_total + kb) * 1024 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1];
-        sdst[j] = scales[(int64_t)kb * N + 16 * nt + c];
+      }
+      if constexpr (WFMT != NV_W_DENSE)
+        sdst[j] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(scales) +
+                                                     ((int64_t)kb * N + 16 * nt) * 2 + s_lane_off);
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------------
+  // A wavefront owns two 32-deep k-steps of every K-block.  The operands of the NEXT k-step (x fragments from LDS,
+  // weights dequantised on the VALU) are produced while the MFMAs of the CURRENT one run, so the matrix pipe, the
+  // VALU and the LDS work at the same time instead of in turn.  Per K-block t:
+  //   phase A: fetch/dequantise (t, step 1);  multiply (t, step 0);  store tile t+1 to the other LDS buffer;  barrier
+  //   phase B: fetch/dequantise (t+1, step 0) from that buffer;      multiply (t, step 1)
+  // One barrier per K-block is enough: tile t+1 replaces tile t-1, whose last reads were issued in phase A of
+  // K-block t-1, before that K-block's barrier.  Global loads run one K-block ahead of their use.
+  auto read_x = [&](int buf, int ks, frag_t (&xf)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = 16 * i + c;
+      xf[i] = *reinterpret_cast<const frag_t*>(&lds_x[buf][row * GEMM_BK + (((4 * ks + g) ^ c) << 3)]);
+    }
+  };
+  auto dequant = [&](const uint32_t (&raw)[NTW][WREG], const uint16_t (&scl)[NTW], int kl, frag_t (&wf)[NTW]) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if constexpr (WFMT == NV_W_DENSE) {
+        wf[j] = __builtin_bit_cast(frag_t, u32x4{raw[j][4 * kl], raw[j][4 * kl + 1], raw[j][4 * kl + 2], raw[j][4 * kl + 3]});
+      } else if constexpr (WFMT == NV_W_INT8) {
+        wf[j] = dequant_w8<T>(raw[j][2 * kl], raw[j][2 * kl + 1], bits_to_f32<T>(scl[j]));
+      } else {
+#ifdef NV_ABL_NODQ
+        wf[j] = __builtin_bit_cast(frag_t, u32x4{raw[j][kl], raw[j][kl], (uint32_t)scl[j], raw[j][kl]});
+#else
+        const float sj = bits_to_f32<T>(scl[j]);
+        wf[j] = dequant_w4<T>(raw[j][kl], sj, -8.0f * sj);
+#endif
+      }
+    }
+  };
+  // keeps a fragment's dequantisation where it was written (next to the MFMAs of the other k-step) instead of
+  // letting the optimiser sink it to its first use behind the barrier
+  auto pin = [&](frag_t (&wf)[NTW]) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(wf[j]));
+  };
+  // multiply one k-step; as soon as the MFMAs of row tile i are issued, x[i] is refilled from LDS with the
+  // fragment of the next k-step, so one set of x registers serves both steps and every read has a whole phase to land.
+  // With STAGE the wavefront also moves its share of the next x tile in between: one 16-byte chunk per thread goes
+  // from registers to the other LDS buffer and the registers are reloaded with the tile after that, so LDS writes
+  // (about a third of the LDS read rate on this chip) trickle in under the MFMAs instead of piling up at the barrier.
+  constexpr int STAGE_EVERY = TM / XV > 0 ? TM / XV : 1;
+  // with three tiles per wavefront there are no registers to spare for staging inside the MFMA stream: the tile is
+  // then stored in one go before the barrier
+  constexpr bool SPREAD_STAGING = NTW * TM <= 16;
+  auto multiply = [&](const frag_t (&wf)[NTW], frag_t (&xf)[TM], bool refill, int buf, int ks, bool stage, int kb_ahead) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        acc[j][i] = mfma16(wf[j], xf[i], acc[j][i]);   // D[n][m]: lane (c, g) reg r = out[m = 16 i + c][n = 4 g + r]
+#ifdef NV_ABL_NOLDSR
+      if (false) {
+#else
+      if (refill) {
+#endif
+        const int row = 16 * i + c;
+        xf[i] = *reinterpret_cast<const frag_t*>(&lds_x[buf][row * GEMM_BK + (((4 * ks + g) ^ c) << 3)]);
+      }
+      if (stage && i % STAGE_EVERY == 0 && i / STAGE_EVERY < XV) {
+        store_x_chunk(buf ^ 1, i / STAGE_EVERY);
+        load_x_chunk(kb_ahead, i / STAGE_EVERY);
+      }
+    }
+  };
+  // scheduling pattern of a phase: per row tile NTW MFMAs, each followed by a few VALU instructions of the
+  // dequantisation, then the LDS refill
+  constexpr int VALU_PER_MFMA = (WFMT == NV_W_DENSE) ? 0 : (28 + TM - 1) / TM;
+  auto interleave = [&](bool refill, bool stage) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VALU_PER_MFMA > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+      }
+      if (refill) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (stage && i % STAGE_EVERY == 0 && i / STAGE_EVERY < XV) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
   };
 
-  if (kb_begin < kb_end) {
+  const int nkb = kb_end - kb_begin;
+  if (nkb > 0) {
+    frag_t xa[TM], wa[NTW], wb[NTW];
     load_x(kb_begin);
     load_w(kb_begin, wr, sc);
     store_x(0);
-  }
-  __syncthreads();
-
-  for (int kb = kb_begin; kb < kb_end; ++kb) {
-    const int buf = (kb - kb_begin) & 1;
-    const bool more = kb + 1 < kb_end;
-    if (more) {
-      load_x(kb + 1);
-      load_w(kb + 1, wn, sn);
-    }
-    float s[NTW], neg136s[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      s[j] = bits_to_f32<T>(sc[j]);
-      neg136s[j] = -8.0f * s[j];
-    }
-#pragma unroll
-    for (int kl = 0; kl < 2; ++kl) {
-      const int ks = 2 * kg + kl;
-      // all x fragments of this k-step first: their LDS latency is covered by the dequantisation below
-      frag_t xf[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = 16 * i + c;
-        xf[i] = *reinterpret_cast<const frag_t*>(&lds_x[buf][row * GEMM_BK + (((4 * ks + g) ^ c) << 3)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the VALU work that hides their latency
-      frag_t wf[NTW];   // dequantised just in time: one k-step of every tile
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        if constexpr (WFMT == NV_W_DENSE)
-          wf[j] = __builtin_bit_cast(frag_t, u32x4{wr[j][4 * kl], wr[j][4 * kl + 1], wr[j][4 * kl + 2], wr[j][4 * kl + 3]});
-        else if constexpr (WFMT == NV_W_INT8)
-          wf[j] = dequant_w8<T>(wr[j][2 * kl], wr[j][2 * kl + 1], s[j]);
-        else
-          wf[j] = dequant_w4<T>(wr[j][kl], s[j], neg136s[j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-          acc[j][i] = mfma16(wf[j], xf[i], acc[j][i]);   // D[n][m]: lane (c, g) reg r = out[m = 16 i + c][n = 4 g + r]
-    }
-    if (more) {
-      store_x(buf ^ 1);
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-        for (int e = 0; e < WREG; ++e) wr[j][e] = wn[j][e];
-        sc[j] = sn[j];
-      }
+    if (nkb > 1) {
+      load_x(kb_begin + 1);
+      load_w(kb_begin + 1, wn, sn);
     }
     __syncthreads();
+    read_x(0, 2 * kg, xa);
+    dequant(wr, sc, 0, wa);
+
+    // One K-block with both phases.  wc/sc_c: raw weights of tile t; wx/sc_x: those of tile t+1 (in flight since
+    // the previous K-block).  After its last use wc is refilled with tile t+2, so two register sets alternate
+    // roles from K-block to K-block and no loaded value is ever copied (a copy would wait for its load).
+    auto kblock = [&](int t, uint32_t (&wc)[NTW][WREG], uint16_t (&sc_c)[NTW], uint32_t (&wx)[NTW][WREG],
+                      uint16_t (&sc_x)[NTW]) {
+      const int buf = t & 1;
+      const int ahead = kb_begin + (t + 2 < nkb ? t + 2 : nkb - 1);   // the last tile is simply fetched again
+      // phase A: multiply (t, step 0); prepare (t, step 1); x tile t+1 (in registers since K-block t-1) -> LDS,
+      // registers <- x tile t+2
+      dequant(wc, sc_c, 1, wb);
+      multiply(wa, xa, true, buf, 2 * kg + 1, SPREAD_STAGING, ahead);
+      pin(wb);
+      interleave(true, SPREAD_STAGING);
+      if (!SPREAD_STAGING) store_x(buf ^ 1);
+#ifndef NV_ABL_NOBAR
+      __syncthreads();
+#endif
+      // phase B: multiply (t, step 1); prepare (t+1, step 0)
+      if (!SPREAD_STAGING) load_x(ahead);
+      dequant(wx, sc_x, 0, wa);
+#ifndef NV_ABL_NOW
+      load_w(ahead, wc, sc_c);
+#endif
+      multiply(wb, xa, true, buf ^ 1, 2 * kg, false, 0);
+      pin(wa);
+      interleave(true, false);
+    };
+    // last K-block: nothing left to fetch
+    auto last_kblock = [&](uint32_t (&wc)[NTW][WREG], uint16_t (&sc_c)[NTW]) {
+      dequant(wc, sc_c, 1, wb);
+      multiply(wa, xa, true, (nkb - 1) & 1, 2 * kg + 1, false, 0);
+      interleave(true, false);
+      multiply(wb, xa, false, 0, 0, false, 0);
+    };
+    int t = 0;
+    for (; t + 2 <= nkb - 1; t += 2) {
+      kblock(t, wr, sc, wn, sn);
+      kblock(t + 1, wn, sn, wr, sc);
+    }
+    if (t < nkb - 1) {
+      kblock(t, wr, sc, wn, sn);
+      last_kblock(wn, sn);
+    } else {
+      last_kblock(wr, sc);
+    }
   }
+  __syncthreads();
 
   // ---- add the second k-step group's accumulators into the first's, through LDS (two passes)
   {
