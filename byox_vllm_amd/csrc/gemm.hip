@@ -23,6 +23,7 @@
 // the kernel is LDS-bound; with 3 (quantised) or 2 (dense) tiles the same read feeds 3 (2) MFMAs and x is re-read
 // from L2 a third (half) as often.  The host picks the factor that leaves the fewest idle CUs.
 #include "common.h"
+#include <stdlib.h>
 
 #define GEMM_BK 128
 
@@ -40,14 +41,50 @@ extern "C" size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
-// Tiles per wavefront: the choice with the smallest makespan on 256 CUs (rounds of workgroups x work per
-// workgroup); ties go to the larger factor, which moves less data through L2 and LDS.
-static int pick_ntw(int ntiles, int64_t mtiles, int split_k, int big) {
-  auto cost = [&](int ntw) {
-    const int64_t blocks = (int64_t)((ntiles + 4 * ntw - 1) / (4 * ntw)) * mtiles * split_k;
-    return ((blocks + 255) / 256) * ntw;
-  };
-  return cost(big) <= cost(1) ? big : 1;
+// ---- launch planning -----------------------------------------------------------
+// Estimated duration (microseconds) of one launch with `ntw` tiles per wavefront and `split_k` K-splits: rounds of
+// workgroups over the 256 CUs x (K-blocks per workgroup x time per K-block + fixed cost), plus the traffic of the
+// fp32 slabs (written here, read by the consumer).  The per-K-block times were measured on MI355X at BM = 128
+// (int4: 0.70 / 1.15 / 2.3 us for 1 / 2 / 3 tiles per wavefront) and scale roughly with the rows per workgroup.
+static double plan_cost(int64_t M, int N, int K, int wfmt, int bm, int ntw, int split_k, bool slabs) {
+  static const double t_quant[4] = {0, 0.70, 1.15, 2.3}, t_dense[3] = {0, 0.60, 1.0};
+  const double t_kb = (wfmt == NV_W_DENSE ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0);
+  const int64_t mtiles = (M + bm - 1) / bm;
+  const int ntiles = N / 16, nkb = K / GEMM_BK;
+  const int64_t blocks = (int64_t)((ntiles + 4 * ntw - 1) / (4 * ntw)) * mtiles * split_k;
+  const int64_t rounds = (blocks + 255) / 256;
+  const int kb_per_block = (nkb + split_k - 1) / split_k;
+  double us = rounds * (kb_per_block * t_kb + 4.0);
+  if (slabs) us += 2.0 * split_k * (double)M * N * 4.0 / 4.0e6;   // slab bytes at ~4 TB/s, written and read once
+  return us;
+}
+
+static int block_rows(int64_t M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128)); }
+
+// Tiles per wavefront for a given split: dense weights take 1 or 2 (16 raw registers per tile), quantised 1 to 3.
+static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) {
+  const int bm = block_rows(M), max_ntw = wfmt == NV_W_DENSE ? 2 : 3;
+  int best = 1;
+  double best_us = plan_cost(M, N, K, wfmt, bm, 1, split_k, slabs);
+  for (int ntw = 2; ntw <= max_ntw; ++ntw) {
+    const double us = plan_cost(M, N, K, wfmt, bm, ntw, split_k, slabs);
+    if (us < best_us) { best_us = us; best = ntw; }
+  }
+  return best;
+}
+
+extern "C" int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt) {
+  if (M <= 0 || N <= 0 || K < GEMM_BK) return 1;
+  const int bm = block_rows(M), max_ntw = wfmt == NV_W_DENSE ? 2 : 3, nkb = K / GEMM_BK;
+  int best = 1;
+  double best_us = 1e30;
+  for (int split = 1; split <= nkb && split <= 32; ++split) {
+    for (int ntw = 1; ntw <= max_ntw; ++ntw) {
+      const double us = plan_cost(M, N, K, wfmt, bm, ntw, split, split > 1);
+      if (us < best_us - 1e-9) { best_us = us; best = split; }
+    }
+  }
+  return best;
 }
 
 extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
@@ -77,10 +114,14 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   GemmArgs a;
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = out; a.os = out_row_stride;
   a.partial = (float*)workspace; a.M = M; a.N = N; a.K = K; a.split_k = split_k; a.wfmt = wfmt;
-  a.bm = M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128));
+  a.bm = block_rows(M);
   const int64_t mtiles = (M + a.bm - 1) / a.bm;
   NV_CHECK_ARG(mtiles <= 65535 && split_k <= 65535, "nv_gemm: M=%lld too large for one launch", (long long)M);
-  a.ntw = pick_ntw(N / 16, mtiles, split_k, wfmt == NV_W_DENSE ? 2 : 3);
+  a.ntw = pick_ntw(M, N, K, wfmt, split_k, use_slabs);
+  if (const char* e = getenv("NV_GEMM_NTW")) {   // measurement aid
+    const int v = atoi(e);
+    if (v >= 1 && v <= (wfmt == NV_W_DENSE ? 2 : 3)) a.ntw = v;
+  }
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.stream = (hipStream_t)stream;
   if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);

@@ -429,9 +429,13 @@ static void gemm_dispatch(const GemmArgs& a) {
   if (a.wfmt == NV_W_DENSE) {
     if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2>(a, grid);
   } else if (a.wfmt == NV_W_INT8) {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1>(a, grid); else gemm_go_epi<T, NV_W_INT8, 3>(a, grid);
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1>(a, grid);
+    else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT8, 2>(a, grid);
+    else gemm_go_epi<T, NV_W_INT8, 3>(a, grid);
   } else {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT4, 1>(a, grid); else gemm_go_epi<T, NV_W_INT4, 3>(a, grid);
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT4, 1>(a, grid);
+    else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT4, 2>(a, grid);
+    else gemm_go_epi<T, NV_W_INT4, 3>(a, grid);
   }
 }
 

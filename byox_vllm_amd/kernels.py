@@ -170,12 +170,9 @@ def silu_mul(x, out=None):
     return out
 
 
-MAX_SPLIT_K = int(os.environ.get("NV_MAX_SPLIT_K", "64"))
-
-
-def pick_split_k(M, N, K, target_blocks=256):
-    tiles = (N // 64) * ((M + 127) // 128)
-    return max(1, min(K // 128, target_blocks // max(tiles, 1), MAX_SPLIT_K))
+def pick_split_k(M, N, K, wfmt=_C.W_INT4):
+    """The library's own choice of split-K for this shape (see nv_gemm_pick_split_k)."""
+    return lib().nv_gemm_pick_split_k(M, N, K, wfmt)
 
 
 def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=False):
@@ -190,7 +187,7 @@ def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=Fa
     if bias is not None:
         assert bias.numel() == N and bias.dtype == x.dtype
     if split_k is None:
-        split_k = 1 if silu_mul else pick_split_k(M, N, K)
+        split_k = 1 if silu_mul else pick_split_k(M, N, K, w.fmt)
     split_k = max(1, min(split_k, K // 128))
     if split_k == 1:
         partial_out = False   # nothing to fuse: the GEMM epilogue writes the finished rows itself

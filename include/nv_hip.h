@@ -145,6 +145,12 @@ int nv_silu_mul(const void* x, void* out, int64_t T, int I, int dtype, nv_stream
 #define NV_GEMM_SILU_MUL 1
 #define NV_GEMM_PARTIAL_OUT 2
 size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k);
+
+/* Split-K factor nv_gemm runs fastest with for this shape on MI355X (>= 1): the planner weighs rounds of
+ * workgroups over the 256 CUs against the traffic of the fp32 slabs.  A caller-chosen split_k is honoured too;
+ * this is the value the host layer uses when the caller has no preference.  No counterpart in the reference
+ * (cuBLAS chooses its own algorithm behind F.linear, nanovllm/layers/linear.py:49). */
+int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt);
 int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
             void* out, int64_t out_row_stride, int64_t M, int N, int K, int wfmt, int split_k,
             void* workspace, size_t workspace_bytes, int flags, int dtype, nv_stream_t stream);

@@ -50,6 +50,21 @@ if __name__ == "__main__":
         run("gate_up", M, 37888, 3584, "w4a16", 4, silu=True)
         run("down", M, 3584, 18944, "w4a16", 4, partial=True)
         run("lm_head", M, 152064, 3584, None, 2)
+    elif which == "sweep7b":
+        for sk in (2, 3, 4, 6, 9):
+            run("down", M, 3584, 18944, "w4a16", 4, split_k=sk, partial=True)
+        for sk in (1, 2, 3, 4, 6):
+            run("qkv", M, 4608, 3584, "w4a16", 8, split_k=sk, partial=True)
+        for sk in (2, 3, 4, 7):
+            run("o", M, 3584, 3584, "w4a16", 8, split_k=sk, partial=True)
+    elif which == "sweep05b":
+        for sk in (2, 4, 7):
+            run("qkv", M, 1152, 896, "w4a16", 24, split_k=sk, partial=True)
+        for sk in (2, 4, 7):
+            run("o", M, 896, 896, "w4a16", 24, split_k=sk, partial=True)
+        for sk in (4, 9, 18, 38):
+            run("down", M, 896, 4864, "w4a16", 24, split_k=sk, partial=True)
+        run("gate_up", M, 9728, 896, "w4a16", 24, silu=True)
     elif which == "gateup7b":
         run("gate_up", M, 37888, 3584, "w4a16", 4, silu=True)
     elif which == "gateup05b":
