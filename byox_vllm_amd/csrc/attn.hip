@@ -236,8 +236,19 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
     rows[0] = r0;
     rows[1] = tok1 < n_keys ? r1 : r0;
   };
+  // Two register sets alternate between "being multiplied" and "being loaded": the loads of the next chunk are
+  // issued before the MFMAs of the current one and nothing is ever copied from a set that is still in flight (a
+  // copy would wait for its loads), so each wavefront keeps one chunk of HBM traffic in flight behind its compute.
+  // Rows are looked up one chunk further ahead than the loads.
   int ch = split * NW + wid;
-  {
+  auto compute = [&](ChunkRegs<T, D>& r, int chunk) {
+    const int base = chunk << 5;
+    if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, r, qf, base, n_keys, n_keys, scale2);
+    else chunk_compute<T, D, true>(st, r, qf, base, n_keys, n_keys, scale2);
+  };
+  if constexpr (D > 64) {
+    // 128-wide heads: two chunks in flight plus the accumulators do not fit 256 registers, so one register set is
+    // loaded ahead and handed over by copy (the 16 KB chunks keep enough bytes in flight per wavefront regardless)
     int64_t rows_cur[2], rows_nxt[2] = {0, 0};
     lookup(ch, rows_cur);
     if (ch < n_chunks) {
@@ -249,12 +260,36 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
         int64_t rows_nn[2] = {0, 0};
         if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
         if (has_next) chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
-        const int base = ch << 5;
-        if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, cur, qf, base, n_keys, n_keys, scale2);
-        else chunk_compute<T, D, true>(st, cur, qf, base, n_keys, n_keys, scale2);
+        compute(cur, ch);
         cur = nxt;
         rows_nxt[0] = rows_nn[0];
         rows_nxt[1] = rows_nn[1];
+      }
+    }
+  } else {
+    int64_t rows_a[2], rows_b[2];
+    lookup(ch, rows_a);
+    if (ch < n_chunks) {
+      lookup(ch + step, rows_b);   // may describe a chunk that does not exist: then it is never used
+      ChunkRegs<T, D> ra, rb;
+      chunk_load<T, D, false>(ra, k_base, v_base, row_stride, rows_a, INT64_MAX);
+      while (true) {
+        if (ch + step >= n_chunks) {
+          compute(ra, ch);
+          break;
+        }
+        lookup(ch + 2 * step, rows_a);
+        chunk_load<T, D, false>(rb, k_base, v_base, row_stride, rows_b, INT64_MAX);
+        compute(ra, ch);
+        ch += step;
+        if (ch + step >= n_chunks) {
+          compute(rb, ch);
+          break;
+        }
+        lookup(ch + 2 * step, rows_b);
+        chunk_load<T, D, false>(ra, k_base, v_base, row_stride, rows_a, INT64_MAX);
+        compute(rb, ch);
+        ch += step;
       }
     }
   }
