@@ -266,6 +266,13 @@ __global__ __launch_bounds__(256) void stage_packed_kernel(const int32_t* __rest
                                                            int64_t* g_ids, int64_t* g_pos, int32_t* g_slots,
                                                            int32_t* g_ctx, int32_t* g_bt, int g_bt_cols, float* g_temps,
                                                            uint64_t* step_counter) {
+  if (bs < 0) {  // header form: the batch size and table width of this step travel in the buffer itself
+    bs = p[0];
+    bt_cols = p[1];
+    p += 2;
+    bs = bs < 0 ? 0 : (bs > padded ? padded : bs);
+    bt_cols = bt_cols < 0 ? 0 : (bt_cols > g_bt_cols ? g_bt_cols : bt_cols);
+  }
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
   for (int i = tid; i < padded; i += nthr) {
     const bool live = i < bs;
@@ -289,10 +296,14 @@ extern "C" int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_
                                       uint64_t* step_counter, nv_stream_t stream) {
   NV_CHECK_ARG(packed && g_ids && g_positions && g_slots && g_context_lens && g_block_tables,
                "nv_stage_decode_packed: null pointer");
-  NV_CHECK_ARG(bs >= 0 && padded_bs >= bs && bt_cols >= 0 && bt_cols <= g_bt_cols,
+  NV_CHECK_ARG(bs < 0 || (padded_bs >= bs && bt_cols >= 0 && bt_cols <= g_bt_cols),
                "nv_stage_decode_packed: bs=%d padded=%d bt_cols=%d g_bt_cols=%d", bs, padded_bs, bt_cols, g_bt_cols);
+  NV_CHECK_ARG(padded_bs >= 0 && g_bt_cols >= 0, "nv_stage_decode_packed: padded=%d g_bt_cols=%d", padded_bs, g_bt_cols);
   if (padded_bs == 0) return NV_OK;
-  int work = bs * bt_cols > padded_bs ? bs * bt_cols : padded_bs;
+  if (bs < 0) bs = -1;
+  // header form: the grid is sized for the largest step the static buffers can take
+  const int rows = bs < 0 ? padded_bs : bs, cols = bs < 0 ? g_bt_cols : bt_cols;
+  int work = rows * cols > padded_bs ? rows * cols : padded_bs;
   int blocks = (work + 255) / 256;
   if (blocks > 64) blocks = 64;
   stage_packed_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(

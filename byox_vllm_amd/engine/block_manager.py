@@ -79,6 +79,7 @@ class BlockManager:
 
     def allocate(self, seq: Sequence) -> None:
         assert not seq.block_table
+        Sequence.table_epoch += 1
         logger.debug("allocating blocks for %s", seq)
         h = -1
         missed = False
@@ -112,6 +113,7 @@ class BlockManager:
                 self._release(block)
         seq.num_cached_tokens = 0
         seq.block_table.clear()
+        Sequence.table_epoch += 1
 
     # -- decode ---------------------------------------------------------------
     def can_append(self, seq: Sequence) -> bool:

@@ -160,25 +160,49 @@ class ModelRunner:
         """Single-rank decode fast path: the step's integers (the values _prepare_decode, _prepare_block_tables and
         _prepare_sample would produce) go to the device as ONE packed buffer; the replayed graph runs staging ->
         forward -> LM head -> sampler; the only host sync is reading the token ids back."""
-        bs, block = len(seqs), self.block_size
+        bs = len(seqs)
         g = self.graph_vars
-        cols = max(len(seq.block_table) for seq in seqs)
-        n = 5 * bs + bs * cols
         host = self._host_stage_np
+        n, cols = self._pack_decode(seqs, host[2:])
+        host[0], host[1] = bs, cols          # header read on the device by the graph's own staging node
+        padded = g["padded_bs"] = next(x for x in self.graph_bs if x >= bs)
+        if padded not in self.graph_stages_itself:
+            self._dev_stage[:n + 2].copy_(self._host_stage[:n + 2], non_blocking=True)
+            kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
+        self._replay(padded)
+        return g["tokens"][:bs].tolist()
+
+    def _pack_decode(self, seqs: list[Sequence], host: np.ndarray) -> tuple[int, int]:
+        """Fill ``host`` (int32) with one decode step's integers, laid out as nv_stage_decode_packed reads them:
+        [last tokens | positions | slots | context lens | temperatures (f32 bits) | block tables bs x cols, -1 padded].
+        Same values as _prepare_decode / _prepare_block_tables / _prepare_sample (nanovllm model_runner.py:152-158,
+        206-235).  Returns (words used, cols).  The padded tables are rebuilt only when a table changed: every
+        change of a table alters the total block count, replaces the list object or bumps Sequence.table_epoch."""
+        bs, block = len(seqs), self.block_size
+        tables_in = [seq.block_table for seq in seqs]
+        lens = list(map(len, tables_in))
+        cols, total = max(lens), sum(lens)
+        n = 5 * bs + bs * cols
+        ntok = np.array([seq.num_tokens for seq in seqs], dtype=np.int32)
         host[0:bs] = [seq.last_token for seq in seqs]
-        host[bs:2 * bs] = [seq.num_tokens - 1 for seq in seqs]
-        host[2 * bs:3 * bs] = [seq.block_table[-1] * block + seq.last_block_num_tokens - 1 for seq in seqs]
-        host[3 * bs:4 * bs] = [seq.num_tokens for seq in seqs]
+        host[bs:2 * bs] = ntok - 1
+        host[2 * bs:3 * bs] = np.array([t[-1] for t in tables_in], dtype=np.int32) * block + (ntok - 1) % block
+        host[3 * bs:4 * bs] = ntok
         host[4 * bs:5 * bs].view(np.float32)[:] = [seq.temperature for seq in seqs]
         tables = host[5 * bs:n].reshape(bs, cols)
-        tables.fill(-1)
-        for i, seq in enumerate(seqs):
-            tables[i, : len(seq.block_table)] = seq.block_table
-        self._dev_stage[:n].copy_(self._host_stage[:n], non_blocking=True)
-        g["padded_bs"] = next(x for x in self.graph_bs if x >= bs)
-        kernels.stage_decode_packed(self._dev_stage, bs, cols, g)
-        self._replay(g["padded_bs"])
-        return g["tokens"][:bs].tolist()
+        key = (tuple(map(id, tables_in)), total, cols, Sequence.table_epoch)
+        cached = getattr(self, "_table_cache", None)
+        if cached is not None and cached[0] == key:
+            tables[:] = cached[1]
+        else:
+            if total == bs * cols:
+                tables[:] = tables_in
+            else:
+                tables.fill(-1)
+                for i, t in enumerate(tables_in):
+                    tables[i, : len(t)] = t
+            self._table_cache = (key, tables.copy())
+        return n, cols
 
     def _prepare_step(self, seqs, is_prefill) -> dict:
         """Host integers of one step as numpy arrays: the whole tensor-parallel control message."""
@@ -358,7 +382,7 @@ class ModelRunner:
             step=torch.zeros(1, dtype=torch.int64, device=dev),     # bumped by the staging kernel on every replay
             padded_bs=max_bs,
         )
-        stage_words = max_bs * (5 + max_blocks)
+        stage_words = 2 + max_bs * (5 + max_blocks)
         self._host_stage = torch.zeros(stage_words, dtype=torch.int32, device="cpu").pin_memory()
         self._host_stage_np = self._host_stage.numpy()
         self._dev_stage = torch.zeros(stage_words, dtype=torch.int32, device=dev)
@@ -369,8 +393,14 @@ class ModelRunner:
         self.graphs, self.graph_pool = {}, None
         self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
-        def forward_rows(lo, hi, k):
+        # padded batch sizes whose graph begins with its own input staging (host buffer -> device -> static inputs)
+        self.graph_stages_itself = set()
+
+        def forward_rows(lo, hi, k, stage_words=0):
             """Decode forward (+ LM head + sampler on a single rank) for rows [lo, hi) of the static buffers."""
+            if stage_words:
+                self._dev_stage[:stage_words].copy_(self._host_stage[:stage_words], non_blocking=True)
+                kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
             self._set_decode_splits(hi - lo)
             set_context(False, slot_mapping=g["slot_mapping"][lo:hi], context_lens=g["context_lens"][lo:hi],
                         block_tables=g["block_tables"][lo:hi])
@@ -386,17 +416,24 @@ class ModelRunner:
         for bs in reversed(self.graph_bs):
             parts = self._microbatch_bounds(bs)
             graphs = []
+            # a single-rank, single-graph step carries its staging inside the graph: the host then only packs the
+            # pinned buffer and launches one graph
+            words = 2 + bs * (5 + max_blocks) if (self.graph_has_head and len(parts) == 1) else 0
+            g["padded_bs"] = bs
+            self._host_stage_np[:2] = 0          # warm-up and capture run on an empty step (all rows padding)
             for k, (lo, hi) in enumerate(parts):
-                forward_rows(lo, hi, k)          # warm-up: sizes every workspace before anything is captured
+                forward_rows(lo, hi, k, words)   # warm-up: sizes every workspace before anything is captured
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, self.graph_pool):
-                    forward_rows(lo, hi, k)
+                    forward_rows(lo, hi, k, words)
                 if self.graph_pool is None:
                     self.graph_pool = graph.pool()
                 graphs.append(graph)
                 torch.cuda.synchronize()
             self.graphs[bs] = graphs
+            if words:
+                self.graph_stages_itself.add(bs)
             reset_context()
         self.graph_vars = g
 

@@ -20,6 +20,9 @@ class SequenceStatus(Enum):
 
 class Sequence:
     counter = count()
+    # Bumped whenever some block table is re-filled (BlockManager.allocate / deallocate): tells a consumer that
+    # caches padded block tables that equal lengths no longer imply equal contents.
+    table_epoch = 0
 
     def __init__(self, token_ids: list[int], block_size: int, sampling_params: SamplingParams | None = None):
         sp = sampling_params if sampling_params is not None else SamplingParams()

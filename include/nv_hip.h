@@ -185,7 +185,10 @@ int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positions, const i
 /* The same staging fed by ONE packed host buffer of 32-bit words
  * [ids(bs) | positions(bs) | slots(bs) | context_lens(bs) | temperatures as float bits(bs) | block_tables(bs*bt_cols)]
  * (one host->device copy per step instead of the reference's five, model_runner.py:216-224,232);
- * also fills g_temperatures (padding rows 1.0) and adds 1 to *step_counter when given. */
+ * also fills g_temperatures (padding rows 1.0) and adds 1 to *step_counter when given.
+ * Header form, bs < 0: the buffer starts with two extra words {bs, bt_cols} read ON THE DEVICE (clamped to
+ * padded_bs / g_bt_cols), so the launch has no per-step host argument and can live inside a captured graph
+ * behind a fixed-size copy of the buffer. */
 int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_cols,
                            int64_t* g_ids, int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
                            int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,

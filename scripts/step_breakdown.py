@@ -36,3 +36,25 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / N * 1e3
 gpu = sum(a.elapsed_time(b) for a, b in spans) / len(spans)
 print(f"wall {wall:.3f} ms/step, graph replay on device {gpu:.3f} ms, host + copies + sync {wall - gpu:.3f} ms")
+
+# host-side split of one step (wall clock of each Python-level piece; the device runs asynchronously under them)
+import numpy as np
+from byox_vllm_amd import kernels as K
+r._replay = replay
+acc = {}
+def timed(name, fn):
+    def w(*a, **k):
+        t = time.perf_counter(); out = fn(*a, **k); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+        return out
+    return w
+r._pack_decode = timed("pack", r._pack_decode)
+r._replay = timed("graph launch", r._replay)
+K.stage_decode_packed = timed("stage launch", K.stage_decode_packed)
+run = r.run
+r.run = timed("run total", run)
+t0 = time.perf_counter()
+for _ in range(N):
+    drv.step()
+torch.cuda.synchronize()
+tot = (time.perf_counter() - t0) / N * 1e6
+print({k: round(v / N * 1e6, 1) for k, v in acc.items()}, f"us per step; whole step {tot:.1f} us (driver bookkeeping = whole - run)")

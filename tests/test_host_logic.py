@@ -250,3 +250,50 @@ def test_sampling_params_and_config_extensions():
         Config("/nonexistent-model-dir")
     with pytest.raises(AssertionError):
         Config("synthetic", hf_config=qwen2_config("qwen2-7b"), tensor_parallel_size=9)
+
+
+def test_pack_decode_matches_prepare_functions_and_tracks_table_changes():
+    """The packed step buffer of the graph path holds exactly what _prepare_decode / _prepare_block_tables /
+    _prepare_sample produce, also after block tables change under the table cache."""
+    import numpy as np
+    from byox_vllm_amd.sampling_params import SamplingParams
+
+    runner = ModelRunner.__new__(ModelRunner)
+    runner.block_size, runner.device = 16, torch.device("cpu")
+    bm = BlockManager(64, 16)
+    seqs = [Sequence(list(range(100, 100 + n)), 16, SamplingParams(temperature=0.5 + 0.1 * i))
+            for i, n in enumerate((5, 16, 17, 40, 32))]
+    for s in seqs:
+        bm.allocate(s)
+    host = np.zeros(4096, dtype=np.int32)
+
+    def check():
+        n, cols = runner._pack_decode(seqs, host)
+        bs = len(seqs)
+        ids, pos = runner._prepare_decode(seqs)
+        c = get_context()
+        assert n == 5 * bs + bs * cols and cols == c.block_tables.size(1)
+        assert host[0:bs].tolist() == ids.tolist() and host[bs:2 * bs].tolist() == pos.tolist()
+        assert host[2 * bs:3 * bs].tolist() == c.slot_mapping.tolist()
+        assert host[3 * bs:4 * bs].tolist() == c.context_lens.tolist()
+        assert host[4 * bs:5 * bs].view(np.float32).tolist() == runner._prepare_sample(seqs).tolist()
+        assert host[5 * bs:n].reshape(bs, cols).tolist() == c.block_tables.tolist()
+        reset_context()
+
+    check()
+    check()                                  # second call is served from the table cache
+    for s in seqs:                           # one decode step: tokens appended, tables may grow
+        s.append_token(7)
+        bm.may_append(s)
+    check()
+    old = list(seqs[3].block_table)          # preemption: same table length afterwards, different block ids
+    bm.deallocate(seqs[3])
+    filler = Sequence([1] * 16, 16)
+    bm.allocate(filler)
+    bm.allocate(seqs[3])
+    assert len(seqs[3].block_table) == len(old) and seqs[3].block_table != old
+    check()
+    seqs[0].block_table = list(seqs[0].block_table)   # replaced list object, equal contents
+    check()
+    seqs.pop()                               # batch composition changes
+    check()

@@ -393,6 +393,44 @@ def test_stage_decode_inputs_pads_like_reference():
     assert g["block_tables"][:, 2:].cpu().eq(9).all()                              # stale columns stay, as in the reference
 
 
+def test_stage_decode_packed_plain_and_header_form():
+    """One packed int32 buffer per step; in the header form batch size and table width are read on the device."""
+    from byox_vllm_amd import kernels
+    padded, gcols = 8, 5
+
+    def fresh():
+        return dict(input_ids=dev(torch.full((8,), 7, dtype=torch.int64)), positions=dev(torch.full((8,), 7, dtype=torch.int64)),
+                    slot_mapping=dev(torch.full((8,), 7, dtype=torch.int32)), context_lens=dev(torch.full((8,), 7, dtype=torch.int32)),
+                    block_tables=dev(torch.full((8, gcols), 9, dtype=torch.int32)), temperatures=dev(torch.zeros(8)),
+                    step=dev(torch.zeros(1, dtype=torch.int64)), padded_bs=padded)
+
+    temps = np.array([0.5, 1.0, 0.0], dtype=np.float32)
+    payload = np.concatenate([[11, 12, 13], [4, 5, 6], [40, 50, 60], [5, 6, 7], temps.view(np.int32), [1, 2, 3, -1, 4, 5]]).astype(np.int32)
+
+    def check(g):
+        assert g["input_ids"].cpu().tolist() == [11, 12, 13, 0, 0, 0, 0, 0]
+        assert g["positions"].cpu().tolist() == [4, 5, 6, 0, 0, 0, 0, 0]
+        assert g["slot_mapping"].cpu().tolist() == [40, 50, 60, -1, -1, -1, -1, -1]
+        assert g["context_lens"].cpu().tolist() == [5, 6, 7, 0, 0, 0, 0, 0]
+        assert g["temperatures"].cpu().tolist() == [0.5, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+        assert g["block_tables"][:3, :2].cpu().tolist() == [[1, 2], [3, -1], [4, 5]]
+        assert g["block_tables"][:, 2:].cpu().eq(9).all() and g["block_tables"][3:].cpu().eq(9).all()
+        assert g["step"].item() == 1
+
+    g = fresh()
+    kernels.stage_decode_packed(dev(torch.from_numpy(payload)), 3, 2, g)
+    check(g)
+    g = fresh()
+    with_header = np.concatenate([[3, 2], payload, np.full(40, 12345)]).astype(np.int32)   # junk behind the step's words
+    kernels.stage_decode_packed(dev(torch.from_numpy(with_header)), -1, 0, g)
+    check(g)
+    # a header that exceeds the static buffers is clamped on the device, never written out of bounds
+    g = fresh()
+    bad = np.concatenate([[100, 100], np.zeros(8 * (5 + gcols), dtype=np.int32)]).astype(np.int32)
+    kernels.stage_decode_packed(dev(torch.from_numpy(bad)), -1, 0, g)
+    assert g["context_lens"].cpu().tolist() == [0] * 8 and g["block_tables"].cpu().eq(0).all()
+
+
 def test_bad_arguments_are_rejected_not_launched():
     from byox_vllm_amd import kernels
     from byox_vllm_amd.layers.quant import LinearWeight
