@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NV_HIP_LIB") or os.path.join(_HERE, "libnv_hip.so")
 
 NV_BF16, NV_F16 = 0, 1
-W_DENSE, W_INT8, W_INT4 = 0, 1, 2
+W_DENSE, W_INT8, W_INT4, W_DENSE_TILED = 0, 1, 2, 3
 GEMM_SILU_MUL, GEMM_PARTIAL_OUT = 1, 2
 
 _p, _i, _i64, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64

@@ -41,6 +41,8 @@ extern "C" size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
+static bool unquantised(int wfmt) { return wfmt == NV_W_DENSE || wfmt == NV_W_DENSE_TILED; }
+
 // ---- launch planning -----------------------------------------------------------
 // Estimated duration (microseconds) of one launch with `ntw` tiles per wavefront and `split_k` K-splits: rounds of
 // workgroups over the 256 CUs x (K-blocks per workgroup x time per K-block + fixed cost), plus the traffic of the
@@ -48,7 +50,7 @@ extern "C" size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k) {
 // (int4: 0.70 / 1.15 / 2.3 us for 1 / 2 / 3 tiles per wavefront) and scale roughly with the rows per workgroup.
 static double plan_cost(int64_t M, int N, int K, int wfmt, int bm, int ntw, int split_k, bool slabs) {
   static const double t_quant[4] = {0, 0.70, 1.15, 2.3}, t_dense[3] = {0, 0.60, 1.0};
-  const double t_kb = (wfmt == NV_W_DENSE ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0);
+  const double t_kb = (unquantised(wfmt) ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0);
   const int64_t mtiles = (M + bm - 1) / bm;
   const int ntiles = N / 16, nkb = K / GEMM_BK;
   const int64_t blocks = (int64_t)((ntiles + 4 * ntw - 1) / (4 * ntw)) * mtiles * split_k;
@@ -63,7 +65,7 @@ static int block_rows(int64_t M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 6
 
 // Tiles per wavefront for a given split: dense weights take 1 or 2 (16 raw registers per tile), quantised 1 to 3.
 static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) {
-  const int bm = block_rows(M), max_ntw = wfmt == NV_W_DENSE ? 2 : 3;
+  const int bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3;
   int best = 1;
   double best_us = plan_cost(M, N, K, wfmt, bm, 1, split_k, slabs);
   for (int ntw = 2; ntw <= max_ntw; ++ntw) {
@@ -75,7 +77,7 @@ static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) 
 
 extern "C" int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt) {
   if (M <= 0 || N <= 0 || K < GEMM_BK) return 1;
-  const int bm = block_rows(M), max_ntw = wfmt == NV_W_DENSE ? 2 : 3, nkb = K / GEMM_BK;
+  const int bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3, nkb = K / GEMM_BK;
   int best = 1;
   double best_us = 1e30;
   for (int split = 1; split <= nkb && split <= 32; ++split) {
@@ -93,11 +95,11 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   const bool silu = (flags & NV_GEMM_SILU_MUL) != 0, slabs_out = (flags & NV_GEMM_PARTIAL_OUT) != 0;
   NV_CHECK_ARG(x && w && (out || slabs_out), "nv_gemm: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_gemm: bad dtype %d", dtype);
-  NV_CHECK_ARG(wfmt == NV_W_DENSE || wfmt == NV_W_INT8 || wfmt == NV_W_INT4, "nv_gemm: bad weight format %d", wfmt);
+  NV_CHECK_ARG(wfmt >= NV_W_DENSE && wfmt <= NV_W_DENSE_TILED, "nv_gemm: bad weight format %d", wfmt);
   NV_CHECK_ARG((flags & ~(NV_GEMM_SILU_MUL | NV_GEMM_PARTIAL_OUT)) == 0 && !(silu && slabs_out), "nv_gemm: unsupported flags %d", flags);
   NV_CHECK_ARG(N > 0 && N % 16 == 0, "nv_gemm: N=%d must be a multiple of 16", N);
   NV_CHECK_ARG(K > 0 && K % GEMM_BK == 0, "nv_gemm: K=%d must be a multiple of %d", K, GEMM_BK);
-  NV_CHECK_ARG(wfmt == NV_W_DENSE || scales, "nv_gemm: quantised weights need scales");
+  NV_CHECK_ARG(unquantised(wfmt) || scales, "nv_gemm: quantised weights need scales");
   NV_CHECK_ARG(x_row_stride % 8 == 0 && out_row_stride % 4 == 0, "nv_gemm: bad row strides");
   NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)out % 8 == 0 && (!bias || (uintptr_t)bias % 8 == 0),
                "nv_gemm: misaligned pointer");
@@ -120,7 +122,7 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   a.ntw = pick_ntw(M, N, K, wfmt, split_k, use_slabs);
   if (const char* e = getenv("NV_GEMM_NTW")) {   // measurement aid
     const int v = atoi(e);
-    if (v >= 1 && v <= (wfmt == NV_W_DENSE ? 2 : 3)) a.ntw = v;
+    if (v >= 1 && v <= (unquantised(wfmt) ? 2 : 3)) a.ntw = v;
   }
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.stream = (hipStream_t)stream;

@@ -108,10 +108,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
     for (int v = 0; v < XV; ++v) store_x_chunk(buf, v);
   };
   // raw weights of this wavefront's two k-steps of one K-block per tile (current and prefetched), and group scales
-  constexpr int WREG = (WFMT == NV_W_DENSE) ? 8 : (WFMT == NV_W_INT8 ? 4 : 2);
+  constexpr bool UNQUANTISED = WFMT == NV_W_DENSE || WFMT == NV_W_DENSE_TILED;
+  constexpr int WREG = UNQUANTISED ? 8 : (WFMT == NV_W_INT8 ? 4 : 2);
   uint32_t wr[NTW][WREG], wn[NTW][WREG];
   uint16_t sc[NTW], sn[NTW];
   const uint32_t w_lane_off = (WFMT == NV_W_DENSE) ? (uint32_t)((c * K + 8 * g) * 2)
+                              : (WFMT == NV_W_DENSE_TILED) ? (uint32_t)(lane * 16)
                               : (WFMT == NV_W_INT8 ? (uint32_t)(lane * 32 + kg * 16) : (uint32_t)(lane * 16 + kg * 8));
   const uint32_t s_lane_off = (uint32_t)(c * 2);
   auto load_w = [&](int kb, uint32_t (&dst)[NTW][WREG], uint16_t (&sdst)[NTW]) {
@@ -126,6 +128,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
           const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 64 * ks);
           dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
         }
+      } else if constexpr (WFMT == NV_W_DENSE_TILED) {   // [N/16][K/128][4 k-steps][64 lanes][8 elements]
+        const char* wp = wb8 + (((int64_t)nt * nkb_total + kb) * 4 + 2 * kg) * 1024 + w_lane_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 1024 * ks);
+          dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
+        }
       } else if constexpr (WFMT == NV_W_INT8) {   // tiled [N/16][K/128][64 lanes][8 dwords]: dwords 4 kg .. 4 kg + 3
         const u32x4 a = *reinterpret_cast<const u32x4*>(wb8 + ((int64_t)nt * nkb_total + kb) * 2048 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1]; dst[j][2] = a[2]; dst[j][3] = a[3];
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
         const u32x2 a = *reinterpret_cast<const u32x2*>(wb8 + ((int64_t)nt * nkb_total + kb) * 1024 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1];
       }
-      if constexpr (WFMT != NV_W_DENSE)
+      if constexpr (!UNQUANTISED)
         sdst[j] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(scales) +
                                                      ((int64_t)kb * N + 16 * nt) * 2 + s_lane_off);
     }
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   auto dequant = [&](const uint32_t (&raw)[NTW][WREG], const uint16_t (&scl)[NTW], int kl, frag_t (&wf)[NTW]) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      if constexpr (WFMT == NV_W_DENSE) {
+      if constexpr (UNQUANTISED) {
         wf[j] = __builtin_bit_cast(frag_t, u32x4{raw[j][4 * kl], raw[j][4 * kl + 1], raw[j][4 * kl + 2], raw[j][4 * kl + 3]});
       } else if constexpr (WFMT == NV_W_INT8) {
         wf[j] = dequant_w8<T>(raw[j][2 * kl], raw[j][2 * kl + 1], bits_to_f32<T>(scl[j]));
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   };
   // scheduling pattern of a phase: per row tile NTW MFMAs, each followed by a few VALU instructions of the
   // dequantisation, then the LDS refill
-  constexpr int VALU_PER_MFMA = (WFMT == NV_W_DENSE) ? 0 : (28 + TM - 1) / TM;
+  constexpr int VALU_PER_MFMA = UNQUANTISED ? 0 : (28 + TM - 1) / TM;
   auto interleave = [&](bool refill, bool stage) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -428,6 +437,8 @@ static void gemm_dispatch(const GemmArgs& a) {
   dim3 grid((ntiles + per_block - 1) / per_block, (unsigned)((a.M + a.bm - 1) / a.bm), a.split_k);
   if (a.wfmt == NV_W_DENSE) {
     if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2>(a, grid);
+  } else if (a.wfmt == NV_W_DENSE_TILED) {
+    if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE_TILED, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE_TILED, 2>(a, grid);
   } else if (a.wfmt == NV_W_INT8) {
     if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1>(a, grid);
     else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT8, 2>(a, grid);

@@ -39,12 +39,24 @@ class ParallelLMHead(VocabParallelEmbedding):
         assert not bias
         super().__init__(num_embeddings, embedding_dim)
 
+    def _streaming_weight(self) -> LinearWeight:
+        """The vocabulary matrix in the layout nv_gemm streams fastest, built once per loaded weight.  The row-major
+        parameter stays: it is what the checkpoint loader fills and what a tied embedding gathers from."""
+        w = self.weight.data
+        key = (w.data_ptr(), w._version)
+        cached = getattr(self, "_tiled", None)
+        if cached is None or cached[0] != key:
+            n, k = w.shape
+            packed = LinearWeight.dense_tiled(w) if (n % 16 == 0 and k % 128 == 0) else LinearWeight.dense(w)
+            cached = self._tiled = (key, packed)
+        return cached[1]
+
     def forward(self, x: torch.Tensor):
         context = get_context()
         if context.is_prefill:
             last = (context.cu_seqlens_q[1:] - 1).long()
             x = x[last].contiguous()
-        logits = kernels.gemm(x, LinearWeight.dense(self.weight.data))
+        logits = kernels.gemm(x, self._streaming_weight())
         if self.tp_size > 1:
             gathered = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
             group = tp_group()

@@ -18,7 +18,7 @@ Scales are stored transposed, [K/128, N].
 
 import torch
 
-from byox_vllm_amd._C import W_DENSE, W_INT4, W_INT8
+from byox_vllm_amd._C import W_DENSE, W_DENSE_TILED, W_INT4, W_INT8
 
 GROUP = 128
 
@@ -69,6 +69,26 @@ class LinearWeight:
     def dense(cls, w: torch.Tensor):
         assert w.dim() == 2 and w.is_contiguous()
         return cls(W_DENSE, w, None, w.size(0), w.size(1), w.dtype)
+
+    @classmethod
+    def dense_tiled(cls, w: torch.Tensor):
+        """Unquantised weights re-ordered for streaming: [N/16][K/128][k-step 4][lane 64][8 elements], lane (c, g) of
+        k-step ks holding W[16 nt + c][128 kb + 32 ks + 8 g + e].  Every 16-byte-per-lane load of a wavefront is then
+        one contiguous KB and a tile's K-blocks follow each other in memory (row-major rows are 2 K bytes apart and
+        give 64-byte pieces).  A copy: the row-major parameter stays what the checkpoint loader and a tied
+        embedding use."""
+        n, k = w.shape
+        assert k % GROUP == 0 and n % 16 == 0, f"weight [{n}, {k}] needs N % 16 == 0 and K % 128 == 0"
+        tiled = w.view(n // 16, 16, k // GROUP, 4, 4, 8).permute(0, 2, 3, 4, 1, 5).contiguous()
+        return cls(W_DENSE_TILED, tiled.view(n // 16, k // GROUP, 4, 64, 8), None, n, k, w.dtype)
+
+    def logical_dense(self):
+        """Row-major [N, K] view of a dense or dense-tiled weight."""
+        if self.fmt == W_DENSE:
+            return self.data
+        assert self.fmt == W_DENSE_TILED
+        n, k = self.out_features, self.in_features
+        return self.data.view(n // 16, k // GROUP, 4, 4, 16, 8).permute(0, 4, 1, 2, 3, 5).reshape(n, k)
 
     @classmethod
     def int4(cls, w: torch.Tensor):

@@ -40,6 +40,7 @@ extern "C" {
 #define NV_W_DENSE 0 /* [N, K] row-major in the model dtype (reference layout, linear.py:24) */
 #define NV_W_INT8 1  /* tiled int8, group-128 scales, see byox_vllm_amd/layers/quant.py */
 #define NV_W_INT4 2  /* tiled int4, group-128 scales, see byox_vllm_amd/layers/quant.py */
+#define NV_W_DENSE_TILED 3 /* model dtype, [N/16][K/128][4 k-steps][64 lanes][8]: every wavefront load is 1 KB contiguous */
 
 typedef void* nv_stream_t;
 

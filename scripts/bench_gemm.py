@@ -8,7 +8,8 @@ from byox_vllm_amd.layers.quant import LinearWeight
 def run(name, M, N, K, fmt, L, split_k=None, silu=False, partial=False, dt=torch.bfloat16):
     dev = "cuda"
     ws = []
-    base = LinearWeight.make((torch.randn(N, K, device=dev) * 0.02).to(dt), fmt)
+    wsrc = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+    base = LinearWeight.dense_tiled(wsrc) if fmt == "tiled" else LinearWeight.make(wsrc, fmt)
     for _ in range(L):
         w = LinearWeight(base.fmt, base.data.clone(), None if base.scales is None else base.scales.clone(), N, K, dt)
         ws.append(w)
@@ -65,6 +66,12 @@ if __name__ == "__main__":
         for sk in (4, 9, 18, 38):
             run("down", M, 896, 4864, "w4a16", 24, split_k=sk, partial=True)
         run("gate_up", M, 9728, 896, "w4a16", 24, silu=True)
+    elif which == "lmhead":
+        for n in (32768, 151936):
+            run("lm_head", M, n, 896, None, 4)
+            run("lm_head", M, n, 896, "tiled", 4)
+        run("lm_head7b", M, 152064, 3584, None, 2)
+        run("lm_head7b", M, 152064, 3584, "tiled", 2)
     elif which == "gateup7b":
         run("gate_up", M, 37888, 3584, "w4a16", 4, silu=True)
     elif which == "gateup05b":

@@ -247,7 +247,7 @@ GEMM_SHAPES = [(1, 128, 128), (7, 192, 256), (32, 1152, 896), (128, 896, 896), (
 
 @pytest.mark.parametrize("name", list(DT))
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("fmt", ["dense", "w8a16", "w4a16"])
+@pytest.mark.parametrize("fmt", ["dense", "tiled", "w8a16", "w4a16"])
 @pytest.mark.parametrize("split_k", [1, 3])
 def test_gemm_dense_and_dequant(name, M, N, K, fmt, split_k):
     """nv_gemm == F.linear on the (dequantised) weight; fp32 accumulation, one rounding at the end."""
@@ -258,7 +258,11 @@ def test_gemm_dense_and_dequant(name, M, N, K, fmt, split_k):
     x = torch.randn(M, K, generator=g).to(dt)
     w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
     bias = (torch.randn(N, generator=g) * 0.1).to(dt)
-    lw = LinearWeight.make(dev(w), None if fmt == "dense" else fmt)
+    if fmt == "tiled":      # unquantised weights in the streaming layout: same values, other order
+        lw = LinearWeight.dense_tiled(dev(w))
+        assert torch.equal(lw.logical_dense().cpu(), w)
+    else:
+        lw = LinearWeight.make(dev(w), None if fmt == "dense" else fmt)
     if fmt == "w4a16":
         packed, scales = lw.logical_int4()
         assert torch.equal(packed.cpu(), Q.quantize_w4(w)[0]) and torch.equal(scales.cpu(), Q.quantize_w4(w)[1])
