@@ -80,7 +80,7 @@ class StepDriver:
 
 def kv_bytes_per_launch(seqs, hf, tp):
     """Algorithmic bytes one paged-attention launch (one layer) must read: K and V of every cached token."""
-    hkv = hf.num_key_value_heads // tp
+    hkv = max(1, hf.num_key_value_heads // tp)
     return sum(len(s) for s in seqs) * 2 * hkv * hf.head_dim * hf.dtype.itemsize
 
 
@@ -90,7 +90,7 @@ def step_bytes(runner, seqs, hf, tp):
     w = sum(m.packed.nbytes for m in runner.model.modules() if isinstance(m, LinearBase))
     head = runner.model.lm_head.weight.numel() * hf.dtype.itemsize
     kv_read = kv_bytes_per_launch(seqs, hf, tp) * hf.num_hidden_layers
-    kv_write = len(seqs) * hf.num_hidden_layers * 2 * (hf.num_key_value_heads // tp) * hf.head_dim * hf.dtype.itemsize
+    kv_write = len(seqs) * hf.num_hidden_layers * 2 * max(1, hf.num_key_value_heads // tp) * hf.head_dim * hf.dtype.itemsize
     return w + head + kv_read + kv_write
 
 
@@ -207,9 +207,9 @@ def main():
     hf = qwen2_config(model_name, dtype=DTYPES[dtype_name])
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     if tp > 1:
-        assert hf.num_attention_heads % tp == 0 and hf.num_key_value_heads % tp == 0, (
-            f"{model_name}: {hf.num_attention_heads}/{hf.num_key_value_heads} heads do not split {tp} ways "
-            "under the reference's sharding rules; use --parallelism dp")
+        assert hf.num_key_value_heads % tp == 0 or tp % hf.num_key_value_heads == 0, (
+            f"{model_name}: {hf.num_key_value_heads} KV heads neither divide nor are divided by {tp} ranks; "
+            "use --parallelism dp")
     block_size = 256
     total_steps = args.warmup + args.steps + 2
     blocks_per_seq = (context + total_steps) // block_size + 1
@@ -253,7 +253,7 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "r01_attn_decode_hbm_traffic.json")
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        if pmc["shape"]["D"] == hf.head_dim and pmc["shape"]["Hkv"] == hf.num_key_value_heads // tp:
+        if pmc["shape"]["D"] == hf.head_dim and pmc["shape"]["Hkv"] == max(1, hf.num_key_value_heads // tp):
             traffic = int(kv_bytes * pmc["traffic_over_algorithmic"])
 
     if rank == 0:

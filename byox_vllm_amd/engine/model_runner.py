@@ -11,6 +11,8 @@ batch 512.
 import pickle
 from multiprocessing.shared_memory import SharedMemory
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -38,7 +40,8 @@ class ModelRunner:
         self.config = config
         hf_config = config.hf_config
         self.block_size = config.kvcache_block_size
-        self.enforce_eager = config.enforce_eager
+        self.enforce_eager = config.enforce_eager or (
+            config.tensor_parallel_size > 1 and os.environ.get("NV_DIST_BACKEND", "nccl") != "nccl")
         self.world_size = config.tensor_parallel_size
         self.rank = rank
         self.event = event
@@ -47,9 +50,11 @@ class ModelRunner:
 
         self._own_pg = False
         if self.world_size > 1 and not dist.is_initialized():
-            dist.init_process_group("nccl", "tcp://127.0.0.1:2333", world_size=self.world_size, rank=rank)
+            # NV_DIST_BACKEND=gloo: rehearsal of the tensor-parallel runtime with the ranks sharing GPUs (RCCL wants one
+            # device per rank); gloo collectives cannot be captured, so that mode runs eagerly
+            dist.init_process_group(os.environ.get("NV_DIST_BACKEND", "nccl"), "tcp://127.0.0.1:2333",
+                                    world_size=self.world_size, rank=rank)
             self._own_pg = True
-        import os
         from byox_vllm_amd.layers.linear import set_tp
         set_tp(rank if self.world_size > 1 else 0, self.world_size, getattr(config, "tp_group", None))
         local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
@@ -344,7 +349,7 @@ class ModelRunner:
 
     def _allocate_kv_cache(self):
         config, hf = self.config, self.config.hf_config
-        num_kv_heads = hf.num_key_value_heads // self.world_size
+        num_kv_heads = self.model.model.layers[0].self_attn.num_kv_heads   # local; replicated when ranks > KV heads
         head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
         block_bytes = 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * head_dim * hf.dtype.itemsize
         if config.num_kvcache_blocks <= 0:

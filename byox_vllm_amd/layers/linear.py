@@ -20,6 +20,78 @@ def divide(numerator, denominator):
     return numerator // denominator
 
 
+K_ALIGN = 128   # nv_gemm walks K in blocks of 128 (= one quantisation group): every K shard is a multiple of it
+
+
+def split_units(total: int, tp_size: int, tp_rank: int) -> tuple[int, int, int]:
+    """Deal ``total`` units to ``tp_size`` ranks as evenly as possible -> (first unit, units owned, padded units).
+    Every rank allocates ``padded`` units (the largest share); the tail of a smaller share is zero.  When
+    ``total`` divides, this is the reference's even chunking (linear.py:62-64,140-145)."""
+    base, extra = divmod(total, tp_size)
+    count = base + (1 if tp_rank < extra else 0)
+    start = tp_rank * base + min(tp_rank, extra)
+    return start, count, base + (1 if extra else 0)
+
+
+class HeadLayout:
+    """Which query / key-value heads one tensor-parallel rank owns, and in which local slots.
+
+    * ``num_kv_heads % tp == 0``: the reference's split (qwen3.py:30-34): contiguous heads, nothing replicated.
+    * ``tp % num_kv_heads == 0`` (more ranks than KV heads, e.g. 28/4 heads on 8 ranks): each KV head is
+      replicated on ``tp / num_kv_heads`` consecutive ranks, which share its query group as evenly as possible
+      (7 heads -> 4 + 3).
+    Local query slots are grouped per local KV head (slot s attends with KV head s // group) and padded with
+    all-zero heads so that every rank has the same shape and ``slots * head_dim`` is a multiple of 128 (the K
+    extent of o_proj).  A zero head has zero q rows/bias and zero o_proj columns: it adds exactly 0 to the
+    row-parallel sum, so the all-reduced result equals the unsharded layer's."""
+
+    def __init__(self, num_heads: int, num_kv_heads: int, head_dim: int, tp_size: int, tp_rank: int):
+        assert num_heads % num_kv_heads == 0, "query heads must be a multiple of KV heads"
+        group = num_heads // num_kv_heads
+        if num_kv_heads % tp_size == 0:
+            per = num_kv_heads // tp_size
+            self.kv_heads = list(range(tp_rank * per, (tp_rank + 1) * per))
+            real = [list(range(kv * group, (kv + 1) * group)) for kv in self.kv_heads]
+            widest = group
+        else:
+            assert tp_size % num_kv_heads == 0, (
+                f"{num_heads}/{num_kv_heads} heads on {tp_size} ranks: KV heads must divide or be divided by the rank count")
+            rep = tp_size // num_kv_heads
+            kv, sub = divmod(tp_rank, rep)
+            start, count, widest = split_units(group, rep, sub)
+            self.kv_heads = [kv]
+            real = [list(range(kv * group + start, kv * group + start + count))]
+        slots = widest
+        if (num_heads * head_dim) % K_ALIGN == 0:    # (toy shapes that nv_gemm could not run anyway stay unpadded)
+            while (slots * len(self.kv_heads) * head_dim) % K_ALIGN:
+                slots += 1
+        assert slots <= 16, "a local GQA group wider than 16 heads does not fit the attention kernel"
+        self.group = slots                                        # query slots per local KV head
+        self.q_heads = [(g[j] if j < len(g) else -1) for g in real for j in range(slots)]   # -1 = zero head
+        self.num_heads = len(self.q_heads)
+        self.num_kv_heads = len(self.kv_heads)
+        self.head_dim = head_dim
+
+    def segments(self, heads):
+        """[(source row of the full tensor, rows, destination row)] for the listed heads (runs merged; -1 skipped)."""
+        d, out = self.head_dim, []
+        for slot, h in enumerate(heads):
+            if h < 0:
+                continue
+            if out and out[-1][0] + out[-1][1] == h * d and out[-1][2] + out[-1][1] == slot * d:
+                out[-1] = (out[-1][0], out[-1][1] + d, out[-1][2])
+            else:
+                out.append((h * d, d, slot * d))
+        return out
+
+
+def copy_segments(dst: torch.Tensor, src: torch.Tensor, dim: int, segments) -> None:
+    """dst = 0 except dst[dst_lo : dst_lo + n] = src[src_lo : src_lo + n] along ``dim`` for every segment."""
+    dst.zero_()
+    for src_lo, n, dst_lo in segments:
+        dst.narrow(dim, dst_lo, n).copy_(src.narrow(dim, src_lo, n))
+
+
 _TP_STATE = None   # (rank, size, process group) once the runner has fixed the tensor-parallel layout
 
 
@@ -96,10 +168,20 @@ class ColumnParallelLinear(LinearBase):
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
-    def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False):
+    def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False, align: int = 1):
+        """align: shard every packed matrix in units of ``align`` rows (the MLP passes 128 so that the matching
+        row-parallel K shards are whole K-blocks); uneven shares are zero-padded to the largest one."""
         self.output_sizes = output_sizes
         self.fused_silu = False
-        super().__init__(input_size, sum(output_sizes), bias)
+        tp_rank, tp_size = _tp()
+        self.align = align
+        # per packed matrix: (first source row, rows owned, rows allocated)
+        self.shards = []
+        for size in output_sizes:
+            assert size % align == 0, f"output size {size} is not a multiple of {align}"
+            start, count, padded = split_units(size // align, tp_size, tp_rank)
+            self.shards.append((start * align, count * align, padded * align))
+        LinearBase.__init__(self, input_size, sum(p for _, _, p in self.shards), bias, 0)
 
     def finalize(self, quantization: str | None = None, fuse_silu: bool = False) -> None:
         """fuse_silu: store gate/up rows interleaved so forward_silu_mul() can apply SiluAndMul in the GEMM epilogue."""
@@ -120,41 +202,49 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         return self._gemm(x, None, out=out, silu_mul=True)
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: int):
-        offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
-        size = self.output_sizes[loaded_shard_id] // self.tp_size
-        dst = param.data.narrow(self.tp_dim, offset, size)
-        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+        offset = sum(p for _, _, p in self.shards[:loaded_shard_id])
+        start, count, padded = self.shards[loaded_shard_id]
+        copy_segments(param.data.narrow(self.tp_dim, offset, padded), loaded_weight, self.tp_dim, [(start, count, 0)])
 
 
 class QKVParallelLinear(ColumnParallelLinear):
     def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
                  total_num_kv_heads: int | None = None, bias: bool = False):
-        _, tp_size = _tp()
+        tp_rank, tp_size = _tp()
         total_num_kv_heads = total_num_kv_heads or total_num_heads
         self.head_size = head_size
-        self.num_heads = divide(total_num_heads, tp_size)
-        self.num_kv_heads = divide(total_num_kv_heads, tp_size)
-        super().__init__(hidden_size, (total_num_heads + 2 * total_num_kv_heads) * head_size, bias)
+        self.layout = HeadLayout(total_num_heads, total_num_kv_heads, head_size, tp_size, tp_rank)
+        self.num_heads = self.layout.num_heads          # local query slots (zero heads included)
+        self.num_kv_heads = self.layout.num_kv_heads
+        LinearBase.__init__(self, hidden_size, (self.num_heads + 2 * self.num_kv_heads) * head_size, bias, 0)
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: str):
         assert loaded_shard_id in ("q", "k", "v")
         q_rows, kv_rows = self.num_heads * self.head_size, self.num_kv_heads * self.head_size
         offset, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[loaded_shard_id]
-        dst = param.data.narrow(self.tp_dim, offset, size)
-        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+        heads = self.layout.q_heads if loaded_shard_id == "q" else self.layout.kv_heads
+        copy_segments(param.data.narrow(self.tp_dim, offset, size), loaded_weight, self.tp_dim, self.layout.segments(heads))
 
 
 class RowParallelLinear(LinearBase):
-    def __init__(self, input_size: int, output_size: int, bias: bool = False):
-        _, tp_size = _tp()
-        super().__init__(divide(input_size, tp_size), output_size, bias, 1)
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, align: int = 1,
+                 input_segments=None, local_input_size: int | None = None):
+        """Input columns are sharded in units of ``align`` (uneven shares zero-padded, see split_units), or taken
+        from explicit ``input_segments`` [(source column, columns, local column)] of width ``local_input_size``
+        (o_proj follows the attention block's HeadLayout)."""
+        tp_rank, tp_size = _tp()
+        if input_segments is None:
+            assert input_size % align == 0, f"input size {input_size} is not a multiple of {align}"
+            start, count, padded = split_units(input_size // align, tp_size, tp_rank)
+            input_segments, local_input_size = [(start * align, count * align, 0)], padded * align
+        self.input_segments = input_segments
+        super().__init__(local_input_size, output_size, bias, 1)
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
         if param.dim() == 1:   # a bias is not sharded along the input dimension
             param.data.copy_(loaded_weight)
             return
-        shard = param.data.size(self.tp_dim)
-        param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
+        copy_segments(param.data, loaded_weight, self.tp_dim, self.input_segments)
 
     def forward(self, x, out=None, partial_out=False):
         """partial_out (single rank only): return the split-K slabs for the following add_rmsnorm to sum."""

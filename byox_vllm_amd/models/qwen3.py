@@ -20,7 +20,7 @@ from byox_vllm_amd.layers.activation import SiluAndMul
 from byox_vllm_amd.layers.attention import Attention
 from byox_vllm_amd.layers.embed_head import ParallelLMHead, VocabParallelEmbedding
 from byox_vllm_amd.layers.layernorm import RMSNorm
-from byox_vllm_amd.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear, _tp
+from byox_vllm_amd.layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from byox_vllm_amd.layers.rotary_embedding import get_rope
 from byox_vllm_amd.utils.context import get_context
 
@@ -30,23 +30,23 @@ class Qwen3Attention(nn.Module):
                  head_dim: int | None = None, rms_norm_eps: float = 1e-06, qkv_bias: bool = False,
                  rope_theta: float = 10000, rope_scaling: tuple | None = None) -> None:
         super().__init__()
-        _, tp_size = _tp()
         self.total_num_heads = num_heads
-        assert self.total_num_heads % tp_size == 0
-        self.num_heads = self.total_num_heads // tp_size
         self.total_num_kv_heads = num_kv_heads
-        assert self.total_num_kv_heads % tp_size == 0
-        self.num_kv_heads = self.total_num_kv_heads // tp_size
         self.head_dim = head_dim or hidden_size // self.total_num_heads
-        self.q_size = self.num_heads * self.head_dim
-        self.kv_size = self.num_kv_heads * self.head_dim
         self.scaling = self.head_dim ** -0.5
         self.qkv_bias = qkv_bias
         self.rms_norm_eps = rms_norm_eps
 
+        # The rank's heads come from the QKV layer's HeadLayout: the reference's split where the KV heads divide
+        # by the rank count (qwen3.py:30-34), KV-head replication with zero-padded query slots otherwise.
         self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, self.total_num_heads,
                                           self.total_num_kv_heads, bias=qkv_bias)
-        self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, hidden_size, bias=False)
+        layout = self.qkv_proj.layout
+        self.num_heads, self.num_kv_heads = layout.num_heads, layout.num_kv_heads
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, hidden_size, bias=False,
+                                        input_segments=layout.segments(layout.q_heads), local_input_size=self.q_size)
         self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
                                    base=rope_theta, rope_scaling=rope_scaling)
         self.attn = Attention(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads)
@@ -76,8 +76,11 @@ class Qwen3Attention(nn.Module):
 class Qwen3MLP(nn.Module):
     def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str) -> None:
         super().__init__()
-        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=False)
-        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False)
+        # shards of the intermediate dimension are whole 128-column K-blocks of down_proj (uneven shares are padded
+        # with zero rows / columns: silu(0) * 0 = 0 meets zero weights)
+        align = 128 if intermediate_size % 128 == 0 else 1
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=False, align=align)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=False, align=align)
         assert hidden_act == "silu"
         self.act_fn = SiluAndMul()
 

@@ -164,3 +164,91 @@ def test_control_message_is_compact_and_complete():
     assert step["block_tables"].shape == (512, 5) and step["temperatures"].dtype == np.float32
     pre = runner._prepare_step(seqs[:3], True)
     assert pre["cu_seqlens_q"].tolist() == [0, 1024, 2049, 3075] and pre["block_tables"] is None
+
+
+def _attention_block(x, wqkv, bqkv, wo, num_slots, num_kv, d):
+    """fp64 attention block on one rank's shard: slot s attends with local KV head s // (slots / kv heads)."""
+    qkv = x @ wqkv.t() + bqkv
+    q, k, v = qkv.split([num_slots * d, num_kv * d, num_kv * d], dim=-1)
+    T = x.size(0)
+    q, k, v = q.view(T, num_slots, d), k.view(T, num_kv, d), v.view(T, num_kv, d)
+    group = num_slots // num_kv
+    outs = []
+    for s in range(num_slots):
+        p = torch.softmax(q[:, s] @ k[:, s // group].t() * d ** -0.5, dim=-1)
+        outs.append(p @ v[:, s // group])
+    return torch.cat(outs, -1) @ wo.t()
+
+
+@pytest.mark.parametrize("H,Hkv,D,tp", [(14, 2, 64, 1), (14, 2, 64, 2), (28, 4, 128, 4), (28, 4, 128, 8), (8, 2, 64, 4),
+                                         (16, 8, 128, 8)])
+def test_head_layout_sum_over_ranks_equals_unsharded(H, Hkv, D, tp):
+    """KV-head replication and zero-padded query slots (more ranks than KV heads, K shards of o_proj kept at
+    multiples of 128) change nothing: the row-parallel sum over all ranks equals the unsharded attention block."""
+    from byox_vllm_amd.layers import linear as LIN
+    g = torch.Generator().manual_seed(H * 131 + tp)
+    hidden, T = 64, 6
+    x = torch.randn(T, hidden, generator=g, dtype=torch.float64)
+    wq, wk, wv = (torch.randn(n * D, hidden, generator=g, dtype=torch.float64) * 0.2 for n in (H, Hkv, Hkv))
+    bq, bk, bv = (torch.randn(n * D, generator=g, dtype=torch.float64) for n in (H, Hkv, Hkv))
+    wo = torch.randn(hidden, H * D, generator=g, dtype=torch.float64) * 0.1
+    want = _attention_block(x, torch.cat((wq, wk, wv)), torch.cat((bq, bk, bv)), wo, H, Hkv, D)
+    total, seen_q = torch.zeros_like(want), []
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        for rank in range(tp):
+            LIN.set_tp(rank, tp)
+            qkv = LIN.QKVParallelLinear(hidden, D, H, Hkv, bias=True)
+            lay = qkv.layout
+            for w, b, sid in ((wq, bq, "q"), (wk, bk, "k"), (wv, bv, "v")):
+                qkv.weight_loader(qkv.weight, w, sid)
+                qkv.weight_loader(qkv.bias, b, sid)
+            o = LIN.RowParallelLinear(H * D, hidden, input_segments=lay.segments(lay.q_heads),
+                                      local_input_size=lay.num_heads * D)
+            o.weight_loader(o.weight, wo)
+            assert (lay.num_heads * D) % 128 == 0 and lay.num_heads % lay.num_kv_heads == 0 and lay.group <= 16
+            if Hkv % tp == 0 and (H // tp * D) % 128 == 0:      # the reference's even split, bit for bit
+                assert lay.q_heads == list(range(rank * H // tp, (rank + 1) * H // tp))
+                assert torch.equal(qkv.weight.data[: lay.num_heads * D], wq.chunk(tp, 0)[rank])
+            seen_q += [h for h in lay.q_heads if h >= 0]
+            total += _attention_block(x, qkv.weight.data, qkv.bias.data, o.weight.data, lay.num_heads, lay.num_kv_heads, D)
+    finally:
+        LIN._TP_STATE = None
+        torch.set_default_dtype(old_dtype)
+    assert sorted(seen_q) == list(range(H))          # every query head lives on exactly one rank
+    assert torch.allclose(total, want, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("inter,tp", [(4864, 2), (18944, 8), (18944, 4), (768, 4), (640, 3)])
+def test_mlp_uneven_shards_sum_over_ranks_equals_unsharded(inter, tp):
+    """Intermediate columns are dealt in whole 128-column K-blocks; uneven shares are zero-padded (18944 = 148 blocks
+    on 8 ranks -> 19,19,19,19,18,18,18,18)."""
+    from byox_vllm_amd.layers import linear as LIN
+    g = torch.Generator().manual_seed(inter + tp)
+    hidden, T = 32, 4
+    x = torch.randn(T, hidden, generator=g, dtype=torch.float64)
+    wg, wu = (torch.randn(inter, hidden, generator=g, dtype=torch.float64) * 0.3 for _ in range(2))
+    wd = torch.randn(hidden, inter, generator=g, dtype=torch.float64) * 0.1
+    silu = torch.nn.functional.silu
+    want = (silu(x @ wg.t()) * (x @ wu.t())) @ wd.t()
+    total, width = torch.zeros_like(want), set()
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        for rank in range(tp):
+            LIN.set_tp(rank, tp)
+            gu = LIN.MergedColumnParallelLinear(hidden, [inter, inter], align=128)
+            gu.weight_loader(gu.weight, wg, 0)
+            gu.weight_loader(gu.weight, wu, 1)
+            down = LIN.RowParallelLinear(inter, hidden, align=128)
+            down.weight_loader(down.weight, wd)
+            gate, up = (x @ gu.weight.data.t()).chunk(2, -1)
+            assert gate.size(1) == down.weight.size(1) and gate.size(1) % 128 == 0
+            width.add(gate.size(1))
+            total += (silu(gate) * up) @ down.weight.data.t()
+    finally:
+        LIN._TP_STATE = None
+        torch.set_default_dtype(old_dtype)
+    assert len(width) == 1                            # same shapes on every rank
+    assert torch.allclose(total, want, rtol=1e-10, atol=1e-10)
