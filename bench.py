@@ -68,7 +68,8 @@ class StepDriver:
     def step(self):
         tokens = self.runner.call("run", self.seqs, False)
         if self.tp > 1:   # only TP rank 0 samples: every rank must feed the same ids into the next step
-            t = torch.tensor(tokens if tokens is not None else [0] * len(self.seqs), device="cuda")
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(tokens if tokens is not None else [0] * len(self.seqs), device=dev)
             dist.broadcast(t, src=0)
             tokens = t.tolist()
         for seq, tok in zip(self.seqs, tokens):
@@ -184,6 +185,9 @@ def main():
     ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
     args = ap.parse_args()
 
+    if os.environ.get("NV_BENCH_FAULT_TIMEOUT"):   # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["NV_BENCH_FAULT_TIMEOUT"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

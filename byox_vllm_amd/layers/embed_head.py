@@ -1,11 +1,10 @@
 """Vocab-parallel embedding and LM head (interface of nanovllm/layers/embed_head.py:9-66)."""
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from byox_vllm_amd import kernels
-from byox_vllm_amd.layers.linear import _tp, tp_group
+from byox_vllm_amd.layers.linear import _tp, tp_all_reduce, tp_gather
 from byox_vllm_amd.layers.quant import LinearWeight
 from byox_vllm_amd.utils.context import get_context
 
@@ -30,7 +29,7 @@ class VocabParallelEmbedding(nn.Module):
         # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
         y = kernels.embed(x, self.weight.data, self.vocab_start_idx)
         if self.tp_size > 1:
-            dist.all_reduce(y, group=tp_group())
+            tp_all_reduce(y)
         return y
 
 
@@ -58,9 +57,6 @@ class ParallelLMHead(VocabParallelEmbedding):
             x = x[last].contiguous()
         logits = kernels.gemm(x, self._streaming_weight())
         if self.tp_size > 1:
-            gathered = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-            group = tp_group()
-            dst = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.gather(logits, gathered, dst, group=group)
+            gathered = tp_gather(logits, self.tp_rank, self.tp_size)
             logits = torch.cat(gathered, -1) if self.tp_rank == 0 else None
         return logits

@@ -105,6 +105,38 @@ def tp_group():
     return _TP_STATE[2] if _TP_STATE is not None else None
 
 
+def _host_hop(group) -> bool:
+    """True when the group's backend cannot take device tensors reliably (gloo rehearsal of the TP runtime)."""
+    return dist.get_backend(group) != "nccl"
+
+
+def tp_all_reduce(t: torch.Tensor) -> None:
+    """Sum ``t`` over the tensor-parallel group in place (RCCL over xGMI; the reference's dist.all_reduce,
+    linear.py:146, embed_head.py:40).  Under a gloo group the data takes a hop through host memory in fp32."""
+    group = tp_group()
+    if t.is_cuda and _host_hop(group):
+        host = t.float().cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def tp_gather(t: torch.Tensor, tp_rank: int, tp_size: int):
+    """Gather ``t`` from every rank onto the group's first rank -> list of tensors there, None elsewhere
+    (embed_head.py:62-65 of the reference)."""
+    group = tp_group()
+    dst = dist.get_global_rank(group, 0) if group is not None else 0
+    if t.is_cuda and _host_hop(group):
+        host = t.float().cpu()
+        parts = [torch.empty_like(host) for _ in range(tp_size)] if tp_rank == 0 else None
+        dist.gather(host, parts, dst, group=group)
+        return [p.to(device=t.device, dtype=t.dtype) for p in parts] if tp_rank == 0 else None
+    parts = [torch.empty_like(t) for _ in range(tp_size)] if tp_rank == 0 else None
+    dist.gather(t, parts, dst, group=group)
+    return parts
+
+
 def _tp():
     if _TP_STATE is not None:
         return _TP_STATE[0], _TP_STATE[1]
@@ -253,5 +285,5 @@ class RowParallelLinear(LinearBase):
             return self._gemm(x, None, partial_out=True)
         y = self._gemm(x, bias, out=out)
         if self.tp_size > 1:
-            dist.all_reduce(y, group=tp_group())
+            tp_all_reduce(y)
         return y
