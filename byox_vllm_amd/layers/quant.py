@@ -111,8 +111,9 @@ class LinearWeight:
 
     @classmethod
     def make(cls, w: torch.Tensor, quantization: str | None):
-        if quantization is None:
-            return cls.dense(w.contiguous())
+        if quantization is None:   # unquantised: the streaming layout when the shape allows it
+            n, k = w.shape
+            return cls.dense_tiled(w.contiguous()) if (n % 16 == 0 and k % GROUP == 0) else cls.dense(w.contiguous())
         return cls.int4(w) if quantization == "w4a16" else cls.int8(w)
 
     # -- logical (untiled) views, used by tests to compare with the CPU oracle's format ----

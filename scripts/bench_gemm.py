@@ -66,6 +66,12 @@ if __name__ == "__main__":
         for sk in (4, 9, 18, 38):
             run("down", M, 896, 4864, "w4a16", 24, split_k=sk, partial=True)
         run("gate_up", M, 9728, 896, "w4a16", 24, silu=True)
+    elif which == "dense05b":
+        for fmt in (None, "tiled"):
+            run("qkv", M, 1152, 896, fmt, 24, partial=True)
+            run("o", M, 896, 896, fmt, 24, partial=True)
+            run("gate_up", M, 9728, 896, fmt, 24, silu=True)
+            run("down", M, 896, 4864, fmt, 24, partial=True)
     elif which == "lmhead":
         for n in (32768, 151936):
             run("lm_head", M, n, 896, None, 4)

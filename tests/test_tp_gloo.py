@@ -23,8 +23,8 @@ def _cpu_kernels():
     from oracle import layers as L
 
     def gemm(x, w, bias=None, out=None, **kw):
-        assert w.fmt == 0
-        return F.linear(x, w.data, bias)
+        assert w.fmt in (0, 3)   # unquantised, row-major or streaming layout
+        return F.linear(x, w.logical_dense(), bias)
 
     def embed(ids, weight, vocab_start=0, out=None):
         ok = (ids >= vocab_start) & (ids < vocab_start + weight.size(0))
