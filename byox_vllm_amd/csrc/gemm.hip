@@ -27,9 +27,12 @@
 
 #define GEMM_BK 128
 
+#include "rope_common.h"
+
 struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
+  RopeArgs rope;   // epi == 3 only
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);
@@ -125,6 +128,7 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
     if (v >= 1 && v <= (unquantised(wfmt) ? 2 : 3)) a.ntw = v;
   }
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
+  a.rope = RopeArgs{};
   a.stream = (hipStream_t)stream;
   if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
   NV_CHECK_LAUNCH();
@@ -132,5 +136,56 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
     if (dtype == NV_BF16) nv_gemm_reduce_bf16(a); else nv_gemm_reduce_f16(a);
     NV_CHECK_LAUNCH();
   }
+  return NV_OK;
+}
+
+
+// q/k/v projection with everything that follows it before attention in one launch: x . Wqkv^T + bias, per-head
+// RMSNorm (Qwen3), RoPE on q and k, q/k/v written to the qkv buffer and k/v to the token's KV-cache row.
+// One workgroup owns one head (64 or 128 columns) over the whole K extent, so nothing is left to reduce.
+extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const void* w, const void* scales,
+                                     const void* bias, void* qkv, int64_t qkv_row_stride, int64_t M, int K, int wfmt,
+                                     const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
+                                     void* k_cache, void* v_cache, const void* q_norm_w, const void* k_norm_w,
+                                     float eps, int H, int Hkv, int D, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(x && w && qkv && positions && cos_sin, "nv_gemm_rope_kv_store: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_gemm_rope_kv_store: bad dtype %d", dtype);
+  NV_CHECK_ARG(wfmt >= NV_W_DENSE && wfmt <= NV_W_DENSE_TILED, "nv_gemm_rope_kv_store: bad weight format %d", wfmt);
+  NV_CHECK_ARG(D == 64 || D == 128, "nv_gemm_rope_kv_store: head_dim %d not in {64, 128}", D);
+  NV_CHECK_ARG(H >= 0 && Hkv >= 0 && H + Hkv > 0, "nv_gemm_rope_kv_store: bad head counts");
+  NV_CHECK_ARG(K > 0 && K % GEMM_BK == 0, "nv_gemm_rope_kv_store: K=%d must be a multiple of %d", K, GEMM_BK);
+  NV_CHECK_ARG(unquantised(wfmt) || scales, "nv_gemm_rope_kv_store: quantised weights need scales");
+  NV_CHECK_ARG((k_cache == nullptr) == (v_cache == nullptr) && (!k_cache || slot_mapping),
+               "nv_gemm_rope_kv_store: k_cache, v_cache and slot_mapping go together");
+  NV_CHECK_ARG((q_norm_w == nullptr) == (k_norm_w == nullptr), "nv_gemm_rope_kv_store: q_norm_w and k_norm_w go together");
+  const int N = (H + 2 * Hkv) * D;
+  NV_CHECK_ARG(x_row_stride % 8 == 0 && qkv_row_stride % 4 == 0 && qkv_row_stride >= N, "nv_gemm_rope_kv_store: bad row strides");
+  NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)w | (uintptr_t)cos_sin) % 16 == 0 &&
+               ((uintptr_t)qkv | (uintptr_t)bias | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)q_norm_w |
+                (uintptr_t)k_norm_w) % 8 == 0, "nv_gemm_rope_kv_store: misaligned pointer");
+  NV_CHECK_ARG(M >= 0, "nv_gemm_rope_kv_store: M=%lld", (long long)M);
+  if (M == 0) return NV_OK;
+  GemmArgs a;
+  a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
+  a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;
+  // rows per workgroup: small tiles until the (head, row tile) grid covers the chip
+  const int heads = H + 2 * Hkv;
+  a.bm = 128;
+  for (int bm : {64, 32, 16})
+    if ((int64_t)heads * ((M + a.bm - 1) / a.bm) < 128) a.bm = bm;
+  if (const char* e = getenv("NV_ROPE_GEMM_BM")) {   // measurement aid
+    const int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64 || v == 128) a.bm = v;
+  }
+  NV_CHECK_ARG((M + a.bm - 1) / a.bm <= 65535, "nv_gemm_rope_kv_store: M=%lld too large for one launch", (long long)M);
+  a.ntw = D / 64;
+  a.epi = 3;
+  a.rope.positions = positions; a.rope.cos_sin = cos_sin; a.rope.slots = slot_mapping;
+  a.rope.k_cache = (uint16_t*)k_cache; a.rope.v_cache = (uint16_t*)v_cache;
+  a.rope.qn_w = (const uint16_t*)q_norm_w; a.rope.kn_w = (const uint16_t*)k_norm_w;
+  a.rope.eps = eps; a.rope.H = H; a.rope.Hkv = Hkv; a.rope.D = D;
+  a.stream = (hipStream_t)stream;
+  if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
+  NV_CHECK_LAUNCH();
   return NV_OK;
 }

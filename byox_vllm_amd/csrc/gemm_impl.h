@@ -1,6 +1,7 @@
 // Templates of the decode GEMM (see gemm.hip for the design notes); instantiated per dtype in gemm_bf16.hip / gemm_f16.hip.
 #pragma once
 #include "common.h"
+#include "rope_common.h"
 
 #define GEMM_BK 128
 
@@ -41,19 +42,22 @@ __device__ __forceinline__ typename VecOf<T>::x8 dequant_w8(uint32_t lo, uint32_
 // A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
 // two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
 // dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
-template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split
+template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
+                                                            //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
 __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                    const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
                                                    int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
-                                                   int K, int split_k) {
+                                                   int K, int split_k, RopeArgs ra) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int TM = BM / 16;                       // 16-row tiles of x per workgroup
   constexpr int XCH = BM * 16;                      // 16-byte chunks in one x tile
   constexpr int XV = (XCH + 511) / 512;             // chunks per thread
   constexpr int RED_REGS = (NTW * TM + 1) / 2;      // accumulator tiles exchanged per reduction pass
   constexpr int LDS_X = 2 * BM * GEMM_BK * 2, LDS_RED = RED_REGS * 256 * 16;
-  constexpr int LDS_BYTES = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+  constexpr int LDS_STAGE = (EPI == 3) ? BM * (64 * NTW + 4) * 4 : 0;   // fp32 rows of one head, padded against conflicts
+  constexpr int LDS_XR = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+  constexpr int LDS_BYTES = LDS_XR > LDS_STAGE ? LDS_XR : LDS_STAGE;
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES];
   uint16_t (*lds_x)[BM * GEMM_BK] = reinterpret_cast<uint16_t (*)[BM * GEMM_BK]>(lds_raw);
 
@@ -322,6 +326,37 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   }
   if (kg == 1) return;
 
+  // ---- RoPE epilogue: the workgroup's 64 NTW columns are exactly one head (blockIdx.x = head slot).  The rotation
+  // pairs element d with d + D/2, which live in different wavefronts, so the finished rows (+bias, rounded to the
+  // model dtype as a plain store would) go through LDS once and are then handled D/8 lanes per row.
+  if constexpr (EPI == 3) {
+    constexpr int DD = 64 * NTW, LD = DD + 4;
+    float* stage = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int col = 16 * (wid * NTW + j) + 4 * g;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (bias) b4 = unpack4<T>(*reinterpret_cast<const u32x2*>(bias + (int64_t)blockIdx.x * DD + col));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        *reinterpret_cast<f32x4*>(&stage[(16 * i + c) * LD + col]) = round4<T>(acc[j][i] + b4);
+    }
+    __syncthreads();   // the four wavefronts that are still here
+    constexpr int LPH = DD / 8, ROWS = 256 / LPH;
+    const int sub = tid & (LPH - 1);
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += ROWS) {
+      const int r = r0 + tid / LPH;
+      const bool live = r < BM && m0 + r < M;
+      const float* src = &stage[(r < BM ? r : 0) * LD];
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 4 * sub);
+      const f32x4 x2 = *reinterpret_cast<const f32x4*>(src + DD / 2 + 4 * sub);
+      const int64_t t = live ? m0 + r : 0;
+      rope_finish<T>(x1, x2, ra, (int)blockIdx.x, t, sub, out + t * out_stride + (int64_t)blockIdx.x * DD, true, live);
+    }
+    return;
+  }
+
   // ---- epilogue: per tile, lane holds columns 16 nt + 4g .. +3 of rows m0 + 16 i + c
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
@@ -404,6 +439,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
+  RopeArgs rope;   // epi == 3 only
 };
 #endif
 
@@ -412,7 +448,7 @@ static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 #define GO(BMV)                                                                                               \
   gemm_kernel<T, WFMT, BMV, NTW, EPI><<<grid, dim3(512), 0, a.stream>>>(                                      \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,  \
-      a.os, a.partial, a.M, a.N, a.K, a.split_k)
+      a.os, a.partial, a.M, a.N, a.K, a.split_k, a.rope)
   switch (a.bm) {
     case 16: GO(16); break;
     case 32: GO(32); break;
@@ -426,7 +462,8 @@ template <typename T, int WFMT, int NTW>
 static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
   if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
   else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
-  else gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
+  else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
+  else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3>(a, grid);   // a head is 64 or 128 columns
 }
 
 // One dtype's instantiations: dense takes 1 or 2 tiles per wavefront (16 raw registers per tile), quantised 1 or 3.

@@ -89,6 +89,13 @@ __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, cons
   const int64_t slab = rows * hidden;
   float v[NV][8];
   float ss = 0.f;
+  // the norm weights are fetched together with the row, not after the reduction: one memory round trip less
+  u32x4 wreg[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * NT;
+    wreg[k] = (i < nvec) ? reinterpret_cast<const u32x4*>(w)[i] : u32x4{0, 0, 0, 0};
+  }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int i = tid + k * NT;
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, cons
   for (int k = 0; k < NV; ++k) {
     const int i = tid + k * NT;
     if (i < nvec) {
-      const u32x4 ww = reinterpret_cast<const u32x4*>(w)[i];
+      const u32x4 ww = wreg[k];
       u32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -8,32 +8,14 @@
 // of the second half, so the rotation needs no cross-lane traffic, every access
 // is 8 or 16 bytes wide, and the per-head norm is a reduction over D/8 lanes.
 #include "common.h"
-
+#include "rope_common.h"
 #include "splitk.h"
 
-template <typename T>
-__device__ __forceinline__ f32x4 unpack4(u32x2 w) {
-  return f32x4{lo_f32<T>(w[0]), hi_f32<T>(w[0]), lo_f32<T>(w[1]), hi_f32<T>(w[1])};
-}
-template <typename T>
-__device__ __forceinline__ u32x2 pack4(f32x4 v) {
-  return u32x2{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-}
-// round to the model dtype and back
-template <typename T>
-__device__ __forceinline__ f32x4 round4(f32x4 v) {
-  return unpack4<T>(pack4<T>(v));
-}
-
 template <typename T, bool PARTIAL>  // PARTIAL: the qkv rows exist only as split-K slabs
-__global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride,
-                                                      const int64_t* __restrict__ positions,
-                                                      const float* __restrict__ cos_sin,
-                                                      const int32_t* __restrict__ slots, uint16_t* k_cache,
-                                                      uint16_t* v_cache, const uint16_t* __restrict__ qn_w,
-                                                      const uint16_t* __restrict__ kn_w, float eps, int64_t ntok, int H,
-                                                      int Hkv, int D, const float* __restrict__ part, int nparts,
+__global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride, RopeArgs ra, int64_t ntok,
+                                                      const float* __restrict__ part, int nparts,
                                                       const uint16_t* __restrict__ bias) {
+  const int D = ra.D, H = ra.H, Hkv = ra.Hkv;
   const int lph = D >> 3;  // lanes per head: 2, 4, 8 or 16
   const int heads = H + 2 * Hkv;
   const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lph;
@@ -41,11 +23,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
   const bool live = item < ntok * heads;
   const int64_t t = live ? item / heads : 0;
   const int hs = live ? (int)(item - t * heads) : 0;
-  const int half = D >> 1;
-  const int c1 = 4 * sub, c2 = half + 4 * sub;  // this lane's columns inside the head
+  const int c1 = 4 * sub, c2 = (D >> 1) + 4 * sub;  // this lane's columns inside the head
   uint16_t* row = qkv + t * row_stride + (int64_t)hs * D;
-  const bool is_q = hs < H, is_k = !is_q && hs < H + Hkv;
-  const int slot = slots ? slots[t] : -1;
 
   f32x4 x1, x2;
   if (PARTIAL) {
@@ -69,52 +48,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
     x1 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c1));
     x2 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c2));
   }
-
-  if (!is_q && !is_k) {  // v head: copy to the cache (and materialise it in the qkv buffer)
-    if (!live) return;
-    const u32x2 w1 = pack4<T>(x1), w2 = pack4<T>(x2);
-    if (PARTIAL) {
-      *reinterpret_cast<u32x2*>(row + c1) = w1;
-      *reinterpret_cast<u32x2*>(row + c2) = w2;
-    }
-    if (v_cache && slot >= 0) {
-      uint16_t* dst = v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D;
-      *reinterpret_cast<u32x2*>(dst + c1) = w1;
-      *reinterpret_cast<u32x2*>(dst + c2) = w2;
-    }
-    return;
-  }
-
-  const uint16_t* nw = is_q ? qn_w : kn_w;
-  if (nw) {  // per-head RMSNorm (Qwen3): fp32 normalise, round, scale by weight in the model dtype
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ss += x1[j] * x1[j] + x2[j] * x2[j];
-    for (int o = lph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float inv = 1.0f / sqrtf(ss / (float)D + eps);
-    const f32x4 w1 = unpack4<T>(*reinterpret_cast<const u32x2*>(nw + c1));
-    const f32x4 w2 = unpack4<T>(*reinterpret_cast<const u32x2*>(nw + c2));
-    x1 = round4<T>(round4<T>(x1 * inv) * w1);
-    x2 = round4<T>(round4<T>(x2 * inv) * w2);
-  }
-  if (!live) return;
-  const float* cs = cos_sin + positions[t] * D;
-  const f32x4 c = *reinterpret_cast<const f32x4*>(cs + c1), sn = *reinterpret_cast<const f32x4*>(cs + c2);
-  f32x4 y1, y2;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    // separate roundings for each product and the sum, as eager fp32 PyTorch does
-    y1[j] = __fsub_rn(__fmul_rn(x1[j], c[j]), __fmul_rn(x2[j], sn[j]));
-    y2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
-  }
-  const u32x2 w1 = pack4<T>(y1), w2 = pack4<T>(y2);
-  *reinterpret_cast<u32x2*>(row + c1) = w1;
-  *reinterpret_cast<u32x2*>(row + c2) = w2;
-  if (is_k && k_cache && slot >= 0) {
-    uint16_t* dst = k_cache + ((int64_t)slot * Hkv + (hs - H)) * D;
-    *reinterpret_cast<u32x2*>(dst + c1) = w1;
-    *reinterpret_cast<u32x2*>(dst + c2) = w2;
-  }
+  rope_finish<T>(x1, x2, ra, hs, t, sub, row, PARTIAL, live);
 }
 
 template <typename T>
@@ -158,11 +92,12 @@ static int rope_launch(void* qkv, int64_t qkv_row_stride, const int64_t* positio
   NV_CHECK_ARG((lanes + 255) / 256 <= 0x7fffffff, "nv_rope_kv_store: T=%lld too large for one launch", (long long)T);
   dim3 grid((unsigned)((lanes + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-#define ROPE_GO(TT, PP)                                                                                               \
-  rope_kv_kernel<TT, PP><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, positions, cos_sin, slot_mapping,    \
-                                                (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)q_norm_w,   \
-                                                (const uint16_t*)k_norm_w, eps, T, H, Hkv, D, partials, num_partials, \
-                                                (const uint16_t*)bias)
+  RopeArgs ra;
+  ra.positions = positions; ra.cos_sin = cos_sin; ra.slots = slot_mapping; ra.k_cache = (uint16_t*)k_cache;
+  ra.v_cache = (uint16_t*)v_cache; ra.qn_w = (const uint16_t*)q_norm_w; ra.kn_w = (const uint16_t*)k_norm_w;
+  ra.eps = eps; ra.H = H; ra.Hkv = Hkv; ra.D = D;
+#define ROPE_GO(TT, PP) \
+  rope_kv_kernel<TT, PP><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, ra, T, partials, num_partials, (const uint16_t*)bias)
   if (dtype == NV_BF16) { if (partials) ROPE_GO(bf16_t, true); else ROPE_GO(bf16_t, false); }
   else                  { if (partials) ROPE_GO(f16_t, true); else ROPE_GO(f16_t, false); }
 #undef ROPE_GO

@@ -101,6 +101,31 @@ def rope_kv_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, sl
     return qkv
 
 
+def gemm_rope_kv_store(x, w, bias, positions, cos_sin, num_heads, num_kv_heads, head_dim, slot_mapping=None,
+                       k_cache=None, v_cache=None, q_norm_w=None, k_norm_w=None, eps=1e-6, out=None):
+    """qkv projection + bias + [head norms] + RoPE + KV-cache store in one launch -> qkv [T, (H+2Hkv)*D]
+    (q and k rotated, v as projected).  ``w``: LinearWeight of the packed q|k|v rows."""
+    require_gpu(x, "gemm_rope_kv_store")
+    T, K = x.shape
+    N = (num_heads + 2 * num_kv_heads) * head_dim
+    assert K == w.in_features and N == w.out_features and x.stride(1) == 1 and x.dtype == w.dtype
+    assert positions.dtype == torch.int64 and positions.numel() == T and positions.is_contiguous()
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous() and cos_sin.size(-1) == head_dim
+    if bias is not None:
+        assert bias.numel() == N and bias.dtype == x.dtype
+    if k_cache is not None:
+        assert slot_mapping is not None and slot_mapping.dtype == torch.int32 and slot_mapping.numel() == T
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == x.dtype
+        assert k_cache.size(-1) == head_dim and k_cache.size(-2) == num_kv_heads
+    if out is None:
+        out = torch.empty(T, N, dtype=x.dtype, device=x.device)
+    check(lib().nv_gemm_rope_kv_store(ptr(x), x.stride(0), ptr(w.data), ptr(w.scales), ptr(bias), ptr(out), out.stride(0),
+                                      T, K, w.fmt, ptr(positions), ptr(cos_sin), ptr(slot_mapping), ptr(k_cache),
+                                      ptr(v_cache), ptr(q_norm_w), ptr(k_norm_w), eps, num_heads, num_kv_heads,
+                                      head_dim, dtype_code(x.dtype), stream()), "nv_gemm_rope_kv_store")
+    return out
+
+
 def kv_store(key, value, k_cache, v_cache, slot_mapping):
     """store_kvcache: key/value [T, Hkv, D] (may be strided views of a qkv buffer)."""
     require_gpu(key, "kv_store")

@@ -12,6 +12,8 @@ arranged around the fused kernels:
 it the Qwen3 block (q_norm / k_norm) is built (qwen3.py:66-68,80-82).
 """
 
+import os
+
 import torch
 from torch import nn
 
@@ -50,21 +52,31 @@ class Qwen3Attention(nn.Module):
         self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim, max_position=max_position,
                                    base=rope_theta, rope_scaling=rope_scaling)
         self.attn = Attention(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads)
+        self.fuse_qkv_rope = os.environ.get("NV_FUSE_QKV_ROPE", "1") != "0"
         if not self.qkv_bias:
             self.q_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
             self.k_norm = RMSNorm(self.head_dim, eps=rms_norm_eps)
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         context = get_context()
-        qkv = self.qkv_proj(hidden_states, partial_out=True)   # split-K slabs + bias, summed inside the RoPE kernel
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0
-        qkv = kernels.rope_kv_store(
-            qkv, positions, self.rotary_emb.cos_sin_cache, self.num_heads, self.num_kv_heads, self.head_dim,
-            slot_mapping=context.slot_mapping if has_cache else None,
-            k_cache=attn.k_cache if has_cache else None, v_cache=attn.v_cache if has_cache else None,
-            q_norm_w=None if self.qkv_bias else self.q_norm.weight.data,
-            k_norm_w=None if self.qkv_bias else self.k_norm.weight.data, eps=self.rms_norm_eps)
+        rope = dict(slot_mapping=context.slot_mapping if has_cache else None,
+                    k_cache=attn.k_cache if has_cache else None, v_cache=attn.v_cache if has_cache else None,
+                    q_norm_w=None if self.qkv_bias else self.q_norm.weight.data,
+                    k_norm_w=None if self.qkv_bias else self.k_norm.weight.data, eps=self.rms_norm_eps)
+        if self.fuse_qkv_rope and self.head_dim in (64, 128):
+            # projection, bias, head norms, RoPE and the KV-cache store in one launch (one workgroup per head)
+            proj = self.qkv_proj
+            if proj.packed is None:
+                proj.finalize(None)
+            qkv = kernels.gemm_rope_kv_store(hidden_states, proj.packed, None if proj.bias is None else proj.bias.data,
+                                             positions, self.rotary_emb.cos_sin_cache, self.num_heads,
+                                             self.num_kv_heads, self.head_dim, **rope)
+        else:
+            qkv = self.qkv_proj(hidden_states, partial_out=True)   # split-K slabs + bias, summed inside the RoPE kernel
+            qkv = kernels.rope_kv_store(qkv, positions, self.rotary_emb.cos_sin_cache, self.num_heads,
+                                        self.num_kv_heads, self.head_dim, **rope)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         q = q.view(-1, self.num_heads, self.head_dim)
         k = k.view(-1, self.num_kv_heads, self.head_dim)

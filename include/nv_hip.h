@@ -152,6 +152,18 @@ size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k);
  * this is the value the host layer uses when the caller has no preference.  No counterpart in the reference
  * (cuBLAS chooses its own algorithm behind F.linear, nanovllm/layers/linear.py:49). */
 int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt);
+
+/* The q/k/v projection and everything between it and attention in ONE launch:
+ *   qkv = to_dtype(x . Wqkv^T + bias)                (QKVParallelLinear, linear.py:92-123, via F.linear :70)
+ *   q, k: optional per-head RMSNorm (qwen3.py:80-82), RoPE (rotary_embedding.py:37-48)
+ *   k, v of token t -> cache row slot_mapping[t]     (store_kvcache, attention.py:34-49)
+ * W holds (H + 2 Hkv) * D rows in any nv_gemm weight format; one workgroup owns one head over the whole K extent,
+ * so there is no split-K workspace.  Arguments as in nv_gemm and nv_rope_kv_store; D is 64 or 128. */
+int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
+                          void* qkv, int64_t qkv_row_stride, int64_t M, int K, int wfmt,
+                          const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
+                          void* k_cache, void* v_cache, const void* q_norm_w, const void* k_norm_w, float eps,
+                          int H, int Hkv, int D, int dtype, nv_stream_t stream);
 int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
             void* out, int64_t out_row_stride, int64_t M, int N, int K, int wfmt, int split_k,
             void* workspace, size_t workspace_bytes, int flags, int dtype, nv_stream_t stream);

@@ -1,5 +1,7 @@
 """HIP kernels through the C ABI against the CPU oracle and the reference-generated goldens."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -395,6 +397,46 @@ def test_stage_decode_inputs_pads_like_reference():
     assert g["context_lens"].cpu().tolist() == [5, 6, 7, 0, 0, 0, 0, 0]             # model_runner.py:250-251
     assert g["block_tables"][:3, :2].cpu().tolist() == bt.tolist()
     assert g["block_tables"][:, 2:].cpu().eq(9).all()                              # stale columns stay, as in the reference
+
+
+@pytest.mark.parametrize("fmt", ["tiled", "w8a16", "w4a16"])
+@pytest.mark.parametrize("d,qk_norm,with_bias", [(64, False, True), (128, True, False), (64, True, True)])
+@pytest.mark.parametrize("T", [1, 9, 130])
+def test_gemm_rope_kv_store_equals_gemm_then_rope(fmt, d, qk_norm, with_bias, T):
+    """The one-launch q/k/v projection (+bias, head norms, RoPE, cache store) writes the same bits as nv_gemm
+    followed by nv_rope_kv_store, for every row-tile size the launch picks."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    g = torch.Generator().manual_seed(T * 13 + d)
+    H, Hkv, K, bs, nb = 4, 2, 256, 16, 12
+    dt = torch.bfloat16
+    N = (H + 2 * Hkv) * d
+    x = torch.randn(T, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.06).to(dt)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt) if with_bias else None
+    qn, kn = ((1 + 0.1 * torch.randn(d, generator=g)).to(dt) for _ in range(2))
+    pos = torch.randint(0, 200, (T,), generator=g)
+    slots = torch.randperm(nb * bs, generator=g)[:T].to(torch.int32)
+    slots[T // 2] = -1
+    table = L.build_cos_sin_cache(d, 256, 1e6)
+    lw = LinearWeight.dense_tiled(dev(w)) if fmt == "tiled" else LinearWeight.make(dev(w), fmt)
+    norms = dict(q_norm_w=dev(qn), k_norm_w=dev(kn)) if qk_norm else {}
+
+    kc1, vc1 = (dev(torch.zeros(nb, bs, Hkv, d, dtype=dt)) for _ in range(2))
+    qkv1 = kernels.gemm(dev(x), lw, None if bias is None else dev(bias), split_k=1)
+    kernels.rope_kv_store(qkv1, dev(pos), dev(table), H, Hkv, d, slot_mapping=dev(slots), k_cache=kc1, v_cache=vc1, **norms)
+
+    for bm in ("16", "32", "64", "128", ""):
+        if bm:
+            os.environ["NV_ROPE_GEMM_BM"] = bm
+        else:
+            os.environ.pop("NV_ROPE_GEMM_BM", None)
+        kc2, vc2 = (dev(torch.zeros(nb, bs, Hkv, d, dtype=dt)) for _ in range(2))
+        qkv2 = kernels.gemm_rope_kv_store(dev(x), lw, None if bias is None else dev(bias), dev(pos), dev(table), H, Hkv, d,
+                                          slot_mapping=dev(slots), k_cache=kc2, v_cache=vc2, **norms)
+        assert torch.equal(qkv2.cpu(), qkv1.cpu()), f"qkv differs at BM={bm or 'auto'}"
+        assert torch.equal(kc2.cpu(), kc1.cpu()) and torch.equal(vc2.cpu(), vc1.cpu())
+    os.environ.pop("NV_ROPE_GEMM_BM", None)
 
 
 def test_stage_decode_packed_plain_and_header_form():
