@@ -37,6 +37,7 @@ _PROTOS = {
     "nv_gemm_workspace_bytes": (_sz, [_i64, _i, _i]),
     "nv_gemm_pick_split_k": (_i, [_i64, _i, _i, _i]),
     "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),
+    "nv_gemm_rope_kv_store_is_faster": (_i, [_i64, _i, _i, _i, _i, _i]),
     "nv_gemm_rope_kv_store": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _p]),
     "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "nv_sample_workspace_bytes": (_sz, [_i]),

@@ -140,6 +140,41 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
 }
 
 
+// Rows per workgroup for the one-launch q/k/v projection (a workgroup = one head over all of K, so the grid is
+// heads x row tiles) and its estimated duration, with the same per-K-block figures as plan_cost.
+static int rope_fused_plan(int64_t M, int K, int wfmt, int heads, int D, double* cost_us) {
+  static const double t_quant[3] = {0, 0.70, 1.15}, t_dense[3] = {0, 0.60, 1.0};
+  const int ntw = D / 64, nkb = K / GEMM_BK;
+  int best = 128;
+  double best_us = 1e30;
+  for (int bm : {128, 64, 32, 16}) {
+    if (bm < 128 && bm >= 2 * M) continue;   // a smaller tile would only add empty rows
+    const double t_kb = (unquantised(wfmt) ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0);
+    const int64_t blocks = (int64_t)heads * ((M + bm - 1) / bm);
+    // fewer than 32 workgroups cannot pull the weights fast enough (measured: 18 workgroups at batch 1 lose to split-K)
+    const double us = blocks < 32 ? 1e29 : (double)((blocks + 255) / 256) * (nkb * t_kb + 4.0);
+    if (us < best_us) { best_us = us; best = bm; }
+  }
+  if (cost_us) *cost_us = best_us;
+  return best;
+}
+
+// 1 when the one-launch projection is estimated faster than nv_gemm (best split-K) followed by the RoPE kernel:
+// true for short K (the 0.5B model), false where each row tile would repeat a long dequantisation (7B).
+extern "C" int nv_gemm_rope_kv_store_is_faster(int64_t M, int K, int wfmt, int H, int Hkv, int D) {
+  if (M <= 0 || K < GEMM_BK || (D != 64 && D != 128)) return 0;
+  const int N = (H + 2 * Hkv) * D, bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3;
+  double fused;
+  rope_fused_plan(M, K, wfmt, H + 2 * Hkv, D, &fused);
+  double split = 1e30;
+  for (int s = 1; s <= K / GEMM_BK && s <= 32; ++s)
+    for (int ntw = 1; ntw <= max_ntw; ++ntw) {
+      const double us = plan_cost(M, N, K, wfmt, bm, ntw, s, s > 1);
+      if (us < split) split = us;
+    }
+  return fused < split + 4.5 ? 1 : 0;   // + the stand-alone RoPE / cache-store launch
+}
+
 // q/k/v projection with everything that follows it before attention in one launch: x . Wqkv^T + bias, per-head
 // RMSNorm (Qwen3), RoPE on q and k, q/k/v written to the qkv buffer and k/v to the token's KV-cache row.
 // One workgroup owns one head (64 or 128 columns) over the whole K extent, so nothing is left to reduce.
@@ -168,11 +203,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   GemmArgs a;
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
   a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;
-  // rows per workgroup: small tiles until the (head, row tile) grid covers the chip
-  const int heads = H + 2 * Hkv;
-  a.bm = 128;
-  for (int bm : {64, 32, 16})
-    if ((int64_t)heads * ((M + a.bm - 1) / a.bm) < 128) a.bm = bm;
+  a.bm = rope_fused_plan(M, K, wfmt, H + 2 * Hkv, D, nullptr);
   if (const char* e = getenv("NV_ROPE_GEMM_BM")) {   // measurement aid
     const int v = atoi(e);
     if (v == 16 || v == 32 || v == 64 || v == 128) a.bm = v;

@@ -65,11 +65,13 @@ class Qwen3Attention(nn.Module):
                     k_cache=attn.k_cache if has_cache else None, v_cache=attn.v_cache if has_cache else None,
                     q_norm_w=None if self.qkv_bias else self.q_norm.weight.data,
                     k_norm_w=None if self.qkv_bias else self.k_norm.weight.data, eps=self.rms_norm_eps)
-        if self.fuse_qkv_rope and self.head_dim in (64, 128):
+        proj = self.qkv_proj
+        if proj.packed is None:
+            proj.finalize(None)
+        if self.fuse_qkv_rope and kernels.lib().nv_gemm_rope_kv_store_is_faster(
+                hidden_states.size(0), proj.packed.in_features, proj.packed.fmt, self.num_heads, self.num_kv_heads,
+                self.head_dim):
             # projection, bias, head norms, RoPE and the KV-cache store in one launch (one workgroup per head)
-            proj = self.qkv_proj
-            if proj.packed is None:
-                proj.finalize(None)
             qkv = kernels.gemm_rope_kv_store(hidden_states, proj.packed, None if proj.bias is None else proj.bias.data,
                                              positions, self.rotary_emb.cos_sin_cache, self.num_heads,
                                              self.num_kv_heads, self.head_dim, **rope)

@@ -159,6 +159,8 @@ int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt);
  *   k, v of token t -> cache row slot_mapping[t]     (store_kvcache, attention.py:34-49)
  * W holds (H + 2 Hkv) * D rows in any nv_gemm weight format; one workgroup owns one head over the whole K extent,
  * so there is no split-K workspace.  Arguments as in nv_gemm and nv_rope_kv_store; D is 64 or 128. */
+int nv_gemm_rope_kv_store_is_faster(int64_t M, int K, int wfmt, int H, int Hkv, int D);  /* planner's estimate: 1 = prefer the
+                                                           one-launch form over nv_gemm + nv_rope_kv_store(_splitk) */
 int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const void* w, const void* scales, const void* bias,
                           void* qkv, int64_t qkv_row_stride, int64_t M, int K, int wfmt,
                           const int64_t* positions, const float* cos_sin, const int32_t* slot_mapping,
