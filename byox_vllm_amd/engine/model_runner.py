@@ -292,7 +292,9 @@ class ModelRunner:
     @torch.inference_mode()
     def _run_model(self, input_ids: torch.Tensor, positions: torch.Tensor, is_prefill: bool):
         bs = input_ids.size(0)
-        if is_prefill or self.enforce_eager or bs > self.max_graph_bs:
+        # single-rank graphs end in the sampler and stage their own inputs (_run_decode_graph): a caller that wants
+        # logits from here gets the eager forward
+        if is_prefill or self.enforce_eager or bs > self.max_graph_bs or self.graph_has_head:
             if not is_prefill:
                 self._set_decode_splits(bs)
             return self.model.compute_logits(self.model(input_ids, positions))
@@ -409,9 +411,11 @@ class ModelRunner:
             self._set_decode_splits(hi - lo)
             set_context(False, slot_mapping=g["slot_mapping"][lo:hi], context_lens=g["context_lens"][lo:hi],
                         block_tables=g["block_tables"][lo:hi])
-            g["outputs"][lo:hi] = self.model(g["input_ids"][lo:hi], g["positions"][lo:hi])
-            if self.graph_has_head:
-                logits = self.model.compute_logits(g["outputs"][lo:hi])
+            hidden = self.model(g["input_ids"][lo:hi], g["positions"][lo:hi])
+            if not self.graph_has_head:
+                g["outputs"][lo:hi] = hidden      # the caller computes logits outside the graph (TP gather)
+            else:                                 # head and sampler inside the graph: no copy of the hidden states
+                logits = self.model.compute_logits(hidden)
                 kernels.sample(logits, g["temperatures"][lo:hi], seed=self.config.seed + 7919 * k,
                                seed_offset=g["step"], out=g["tokens"][lo:hi])
 
