@@ -91,11 +91,22 @@ extern "C" int nv_embed(const int64_t* ids, const void* weight, void* out, int64
 // row maximum are common to the row, and log is monotonic, so one pass over the logits suffices.
 // Stage 1: grid (splits, B), each workgroup scans a slice of the row with 16-byte loads and writes
 // its best (score, index); stage 2: one wavefront per row picks the winner (lowest index on ties).
-__device__ __forceinline__ uint32_t mix32(uint64_t z) {  // splitmix64 finaliser
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser: one per (launch, row)
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return (uint32_t)((z ^ (z >> 31)) >> 32);
+  return z ^ (z >> 31);
+}
+// Per-element random bits: a 32-bit avalanche hash (two multiplies; 64-bit multiplies are several quarter-rate
+// instructions each on this chip and made the sampler VALU-bound) of the index keyed by the row's 64-bit key.
+__device__ __forceinline__ uint32_t mix32(uint32_t x, uint32_t k0, uint32_t k1) {
+  x ^= k0;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x ^ k1;
 }
 
 struct Best {
@@ -124,7 +135,7 @@ __device__ __forceinline__ float sample_score(float l, int b, int v, int V, floa
   if (noise) {
     e = noise[(int64_t)b * V + v];
   } else {  // Exp(1) = -log(U), U uniform in (0, 1]
-    const uint32_t r = mix32(seed ^ ((uint64_t)b << 32) ^ (uint64_t)v);
+    const uint32_t r = mix32((uint32_t)v, (uint32_t)seed, (uint32_t)(seed >> 32));
     e = -__logf(((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f));
   }
   return l * inv_temp - __logf(fmaxf(e, 1e-10f));
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const uint16_t* __r
   __shared__ int s_idx[4];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (seed_offset) seed += seed_offset[0] * 0x9e3779b97f4a7c15ull;   // per-replay stream inside a captured graph
+  seed = mix64(seed ^ ((uint64_t)b << 32));                          // this row's key
   const uint16_t* row = logits + (int64_t)b * row_stride;
   const float temp = temps[b];
   const bool greedy = temp == 0.0f;
