@@ -51,28 +51,40 @@ static bool unquantised(int wfmt) { return wfmt == NV_W_DENSE || wfmt == NV_W_DE
 // workgroups over the 256 CUs x (K-blocks per workgroup x time per K-block + fixed cost), plus the traffic of the
 // fp32 slabs (written here, read by the consumer).  The per-K-block times were measured on MI355X at BM = 128
 // (int4: 0.70 / 1.15 / 2.3 us for 1 / 2 / 3 tiles per wavefront) and scale roughly with the rows per workgroup.
-static double plan_cost(int64_t M, int N, int K, int wfmt, int bm, int ntw, int split_k, bool slabs) {
+static int block_rows(int64_t M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128)); }
+
+// Rows per workgroup.  Short K loops (<= 5 K-blocks per workgroup, one tile per wavefront) are dominated by the
+// prologue and epilogue: 64-row tiles need under 128 registers, so two workgroups share a CU and hide each other's
+// fixed cost (measured at batch 128: o 4.5 -> 3.8 us, down 7.0 -> 6.0 us).  Long loops lose by it (the co-resident
+// workgroups repeat the dequantisation: 7B down 27 -> 35 us, LM head 90 -> 126 us) and keep 128 rows.
+static int plan_rows(int64_t M, int K, int ntw, int split_k) {
+  const int kb_per_block = (K / GEMM_BK + split_k - 1) / split_k;
+  return (M > 64 && ntw == 1 && kb_per_block <= 5) ? 64 : block_rows(M);
+}
+
+static double plan_cost(int64_t M, int N, int K, int wfmt, int ntw, int split_k, bool slabs) {
   static const double t_quant[4] = {0, 0.70, 1.15, 2.3}, t_dense[3] = {0, 0.60, 1.0};
-  const double t_kb = (unquantised(wfmt) ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0);
+  const int bm = plan_rows(M, K, ntw, split_k);
+  const bool paired = M > 64 && bm == 64;            // two workgroups per CU
+  const double t_kb = (unquantised(wfmt) ? t_dense[ntw] : t_quant[ntw]) * (0.4 + 0.6 * bm / 128.0) * (paired ? 1.4 : 1.0);
   const int64_t mtiles = (M + bm - 1) / bm;
   const int ntiles = N / 16, nkb = K / GEMM_BK;
   const int64_t blocks = (int64_t)((ntiles + 4 * ntw - 1) / (4 * ntw)) * mtiles * split_k;
-  const int64_t rounds = (blocks + 255) / 256;
+  const int64_t slots = paired ? 512 : 256;
+  const int64_t rounds = (blocks + slots - 1) / slots;
   const int kb_per_block = (nkb + split_k - 1) / split_k;
-  double us = rounds * (kb_per_block * t_kb + 4.0);
+  double us = rounds * (kb_per_block * t_kb + (paired ? 3.0 : 4.0));
   if (slabs) us += 2.0 * split_k * (double)M * N * 4.0 / 4.0e6;   // slab bytes at ~4 TB/s, written and read once
   return us;
 }
 
-static int block_rows(int64_t M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128)); }
-
 // Tiles per wavefront for a given split: dense weights take 1 or 2 (16 raw registers per tile), quantised 1 to 3.
 static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) {
-  const int bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3;
+  const int max_ntw = unquantised(wfmt) ? 2 : 3;
   int best = 1;
-  double best_us = plan_cost(M, N, K, wfmt, bm, 1, split_k, slabs);
+  double best_us = plan_cost(M, N, K, wfmt, 1, split_k, slabs);
   for (int ntw = 2; ntw <= max_ntw; ++ntw) {
-    const double us = plan_cost(M, N, K, wfmt, bm, ntw, split_k, slabs);
+    const double us = plan_cost(M, N, K, wfmt, ntw, split_k, slabs);
     if (us < best_us) { best_us = us; best = ntw; }
   }
   return best;
@@ -80,12 +92,12 @@ static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) 
 
 extern "C" int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt) {
   if (M <= 0 || N <= 0 || K < GEMM_BK) return 1;
-  const int bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3, nkb = K / GEMM_BK;
+  const int max_ntw = unquantised(wfmt) ? 2 : 3, nkb = K / GEMM_BK;
   int best = 1;
   double best_us = 1e30;
   for (int split = 1; split <= nkb && split <= 32; ++split) {
     for (int ntw = 1; ntw <= max_ntw; ++ntw) {
-      const double us = plan_cost(M, N, K, wfmt, bm, ntw, split, split > 1);
+      const double us = plan_cost(M, N, K, wfmt, ntw, split, split > 1);
       if (us < best_us - 1e-9) { best_us = us; best = split; }
     }
   }
@@ -119,14 +131,18 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   GemmArgs a;
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = out; a.os = out_row_stride;
   a.partial = (float*)workspace; a.M = M; a.N = N; a.K = K; a.split_k = split_k; a.wfmt = wfmt;
-  a.bm = block_rows(M);
-  const int64_t mtiles = (M + a.bm - 1) / a.bm;
-  NV_CHECK_ARG(mtiles <= 65535 && split_k <= 65535, "nv_gemm: M=%lld too large for one launch", (long long)M);
   a.ntw = pick_ntw(M, N, K, wfmt, split_k, use_slabs);
   if (const char* e = getenv("NV_GEMM_NTW")) {   // measurement aid
     const int v = atoi(e);
     if (v >= 1 && v <= (unquantised(wfmt) ? 2 : 3)) a.ntw = v;
   }
+  a.bm = silu ? block_rows(M) : plan_rows(M, K, a.ntw, split_k);
+  if (const char* e = getenv("NV_GEMM_BM")) {   // measurement aid
+    const int v = atoi(e);
+    if (v == 16 || v == 32 || v == 64 || v == 128) a.bm = v;
+  }
+  const int64_t mtiles = (M + a.bm - 1) / a.bm;
+  NV_CHECK_ARG(mtiles <= 65535 && split_k <= 65535, "nv_gemm: M=%lld too large for one launch", (long long)M);
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.rope = RopeArgs{};
   a.stream = (hipStream_t)stream;
@@ -163,13 +179,13 @@ static int rope_fused_plan(int64_t M, int K, int wfmt, int heads, int D, double*
 // true for short K (the 0.5B model), false where each row tile would repeat a long dequantisation (7B).
 extern "C" int nv_gemm_rope_kv_store_is_faster(int64_t M, int K, int wfmt, int H, int Hkv, int D) {
   if (M <= 0 || K < GEMM_BK || (D != 64 && D != 128)) return 0;
-  const int N = (H + 2 * Hkv) * D, bm = block_rows(M), max_ntw = unquantised(wfmt) ? 2 : 3;
+  const int N = (H + 2 * Hkv) * D, max_ntw = unquantised(wfmt) ? 2 : 3;
   double fused;
   rope_fused_plan(M, K, wfmt, H + 2 * Hkv, D, &fused);
   double split = 1e30;
   for (int s = 1; s <= K / GEMM_BK && s <= 32; ++s)
     for (int ntw = 1; ntw <= max_ntw; ++ntw) {
-      const double us = plan_cost(M, N, K, wfmt, bm, ntw, s, s > 1);
+      const double us = plan_cost(M, N, K, wfmt, ntw, s, s > 1);
       if (us < split) split = us;
     }
   return fused < split + 4.5 ? 1 : 0;   // + the stand-alone RoPE / cache-store launch
