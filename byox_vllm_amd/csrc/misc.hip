@@ -126,6 +126,7 @@ __device__ __forceinline__ Best wave_best(Best best) {
 }
 
 #define SAMPLE_SPLITS 8
+#define LOG2E_F 1.4426950408889634f
 
 template <typename T>
 __device__ __forceinline__ float sample_score(float l, int b, int v, int V, float inv_temp, bool greedy,
@@ -205,7 +206,197 @@ __global__ __launch_bounds__(256) void sample_final_kernel(const float* __restri
   if (lane == 0) tokens[b] = best.i;
 }
 
-extern "C" size_t nv_sample_workspace_bytes(int B) { return (size_t)B * SAMPLE_SPLITS * 8; }
+// ---- sampling without injected noise: inverse CDF --------------------------------------------------------------
+// Drawing a token from softmax(l / T) by the Gumbel / exponential-noise argmax costs a hash and two logarithms per
+// logit (VALU-bound: 30 us for 128 x 152k logits).  With the noise drawn in-kernel anyway, the same distribution comes
+// cheaper from the inverse CDF with ONE uniform per row: stage 1 (grid (splits, B)) gives every slice its maximum m_k
+// (also the greedy candidate) and s_k = sum exp((l - m_k) / T); stage 2 (one workgroup per row) picks the slice by
+// the weights s_k exp((m_k - M) / T), then walks that slice's prefix sums to the token.  One exp per logit.
+template <typename T>
+__device__ __forceinline__ void load8(const uint16_t* __restrict__ row, int i, int V, bool vec_ok, float (&x)[8]) {
+  if (vec_ok) {
+    const u32x4 t = reinterpret_cast<const u32x4*>(row)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[2 * j] = lo_f32<T>(t[j]);
+      x[2 * j + 1] = hi_f32<T>(t[j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (8 * i + j < V) ? bits_to_f32<T>(row[8 * i + j]) : -INFINITY;
+  }
+}
+
+// 2^x by the hardware instruction alone (arguments here are <= 0 and results only feed sums: no denormal care)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {   // 256 threads, result in every thread
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+#define SAMPLE_QUARTERS 4   // wavefronts per slice: each owns a contiguous quarter and reports its own mass
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_cdf_scan_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                              const float* __restrict__ temps, float* __restrict__ pv,
+                                                              int* __restrict__ pi, float* __restrict__ ps, int V) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint16_t* row = logits + (int64_t)b * row_stride;
+  const float temp = temps[b];
+  const bool vec_ok = (V % 8 == 0) && (row_stride % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
+  const int nvec = (V + 7) >> 3;
+  const int per = (nvec + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
+  const int v0 = blockIdx.x * per;
+  const int v1 = v0 + per < nvec ? v0 + per : nvec;
+  const int quarter = (per + SAMPLE_QUARTERS - 1) / SAMPLE_QUARTERS;
+  const int q0 = v0 + wid * quarter, q1 = (q0 + quarter < v1) ? q0 + quarter : v1;
+  // one pass: every thread keeps its best (value, index) and, for sampled rows, the sum of exp((x - best) / T)
+  // relative to its own running maximum (rescaled when the maximum moves)
+  const bool sampled = temp != 0.0f;
+  const float c = sampled ? LOG2E_F / temp : 0.f;
+  Best best = {-INFINITY, 0x7fffffff};
+  float sum = 0.f;
+  for (int i = q0 + lane; i < q1; i += 64) {
+    float x[8];
+    load8<T>(row, i, V, vec_ok, x);
+    Best vb = {x[0], 8 * i};
+#pragma unroll
+    for (int j = 1; j < 8; ++j) vb = better(vb, Best{x[j], 8 * i + j});
+    if (sampled && vb.v > -INFINITY) {
+      const float m_new = fmaxf(best.v, vb.v);
+      float add = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) add += fast_exp2((x[j] - m_new) * c);
+      sum = sum * fast_exp2((best.v - m_new) * c) + add;   // best.v == -inf: sum is 0 and the factor exp2(-inf) = 0
+    }
+    best = better(best, vb);
+  }
+  const float my_max = best.v;
+  best = wave_best(best);
+  if (lane == 0) {
+    s_val[wid] = best.v;
+    s_idx[wid] = best.i;
+  }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) best = better(best, Best{s_val[w], s_idx[w]});   // the slice's best, in every thread
+  if (sampled && my_max > -INFINITY) sum *= fast_exp2((my_max - best.v) * c);
+  else sum = 0.f;
+  sum = wave_sum(sum);                     // this quarter's mass relative to the slice maximum
+  const int slice = b * SAMPLE_SPLITS + blockIdx.x;
+  if (lane == 0) ps[slice * SAMPLE_QUARTERS + wid] = sum;
+  if (tid == 0) {
+    pv[slice] = best.v;
+    pi[slice] = best.i;
+  }
+}
+
+// One wavefront per row: choose (slice, quarter) by the reported masses, then walk that quarter 64 vectors at a time
+// (lane l takes vector base + l: coalesced; four batches of loads in flight) with a prefix scan over the lanes.
+template <typename T>
+__global__ __launch_bounds__(64) void sample_cdf_pick_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                             const float* __restrict__ temps,
+                                                             const float* __restrict__ pv, const int* __restrict__ pi,
+                                                             const float* __restrict__ ps, int64_t* __restrict__ tokens,
+                                                             int V, uint64_t seed,
+                                                             const uint64_t* __restrict__ seed_offset) {
+  constexpr int NP = SAMPLE_SPLITS * SAMPLE_QUARTERS;   // 32 parts per row: one lane each
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float temp = temps[b];
+  const int part_k = (lane < NP ? lane : NP - 1) / SAMPLE_QUARTERS;
+  const float m_part = pv[b * SAMPLE_SPLITS + part_k];
+  const int i_part = pi[b * SAMPLE_SPLITS + part_k];
+  const float s_part = lane < NP ? ps[b * NP + lane] : 0.f;
+  const Best top = wave_best(Best{m_part, i_part});
+  if (temp == 0.0f || !(top.v > -INFINITY)) {   // greedy (or a row without a finite logit)
+    if (lane == 0) tokens[b] = top.i;
+    return;
+  }
+  const float c = LOG2E_F / temp;
+  if (seed_offset) seed += seed_offset[0] * 0x9e3779b97f4a7c15ull;   // per-replay stream inside a captured graph
+  const uint64_t key = mix64(seed ^ ((uint64_t)b << 32));
+  const float u = ((float)(uint32_t)(key >> 40) + 0.5f) * (1.0f / 16777216.0f);   // uniform in (0, 1)
+  const float weight = s_part > 0.f ? s_part * fast_exp2((m_part - top.v) * c) : 0.f;
+  float cum = weight;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(cum, o, 64);
+    if (lane >= o) cum += up;
+  }
+  const float target = u * __shfl(cum, 63, 64);
+  // the first part with mass whose running total reaches the target; rounding may leave none: take the last with mass
+  const unsigned long long reach = __ballot(weight > 0.f && cum >= target);
+  const unsigned long long any = __ballot(weight > 0.f);
+  const int sel = reach ? __ffsll((long long)reach) - 1 : 63 - __clzll((long long)any);
+  const float m_sel = __shfl(m_part, sel, 64);
+  const float resid = (target - (__shfl(cum, sel, 64) - __shfl(weight, sel, 64))) / fast_exp2((m_sel - top.v) * c);
+  int token = __shfl(i_part, sel, 64);          // fall-back: the selected slice's best token
+
+  const uint16_t* row = logits + (int64_t)b * row_stride;
+  const bool vec_ok = (V % 8 == 0) && (row_stride % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
+  const int nvec = (V + 7) >> 3;
+  const int per = (nvec + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
+  const int quarter = (per + SAMPLE_QUARTERS - 1) / SAMPLE_QUARTERS;
+  const int v0 = (sel / SAMPLE_QUARTERS) * per;
+  const int v1 = v0 + per < nvec ? v0 + per : nvec;
+  const int q0 = v0 + (sel % SAMPLE_QUARTERS) * quarter, q1 = (q0 + quarter < v1) ? q0 + quarter : v1;
+  float running = 0.f;
+  bool done = false;
+  for (int base = q0; base < q1 && !done; base += 256) {
+    float p[4][8];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {               // four batches of loads in flight
+      const int i = base + 64 * u4 + lane;
+      float x[8];
+      if (i < q1) load8<T>(row, i, V, vec_ok, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[u4][j] = (i < q1) ? fast_exp2((x[j] - m_sel) * c) : 0.f;
+    }
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+      if (done) break;
+      const int i = base + 64 * u4 + lane;
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += p[u4][j];
+      float incl = part;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      const float excl = running + incl - part;
+      const bool mine = part > 0.f && excl < resid && resid <= running + incl;
+      if (mine) {
+        float acc = excl;
+        int pick = -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc += p[u4][j];
+          if (pick < 0 && p[u4][j] > 0.f && acc >= resid) pick = 8 * i + j;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)                 // rounding: the last token of the vector that carries mass
+          if (pick < 0 && p[u4][7 - j] > 0.f) pick = 8 * i + 7 - j;
+        token = pick;
+      }
+      const unsigned long long found = __ballot(mine);
+      if (found) {
+        token = __shfl(token, __ffsll((long long)found) - 1, 64);
+        done = true;
+      }
+      running += __shfl(incl, 63, 64);
+    }
+  }
+  if (lane == 0) tokens[b] = token;
+}
+
+extern "C" size_t nv_sample_workspace_bytes(int B) { return (size_t)B * SAMPLE_SPLITS * (8 + 4 * SAMPLE_QUARTERS); }
 
 extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
                          int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
@@ -220,6 +411,22 @@ extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const fl
   float* pv = (float*)workspace;
   int* pi = (int*)(pv + (size_t)B * SAMPLE_SPLITS);
   dim3 grid(SAMPLE_SPLITS, B);
+  if (!noise) {   // greedy rows and in-kernel randomness: maxima + partition sums, then one inverse-CDF draw per row
+    float* ps = (float*)(pi + (size_t)B * SAMPLE_SPLITS);
+    if (dtype == NV_BF16) {
+      sample_cdf_scan_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, pv, pi, ps, V);
+      NV_CHECK_LAUNCH();
+      sample_cdf_pick_kernel<bf16_t><<<dim3(B), dim3(64), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
+                                                                   pv, pi, ps, tokens, V, seed, seed_offset);
+    } else {
+      sample_cdf_scan_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, pv, pi, ps, V);
+      NV_CHECK_LAUNCH();
+      sample_cdf_pick_kernel<f16_t><<<dim3(B), dim3(64), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
+                                                                  pv, pi, ps, tokens, V, seed, seed_offset);
+    }
+    NV_CHECK_LAUNCH();
+    return NV_OK;
+  }
   if (dtype == NV_BF16)
     sample_partial_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
                                                              noise, pv, pi, V, seed, seed_offset);

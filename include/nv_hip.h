@@ -180,7 +180,9 @@ int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int h
  * Exp(1): read from `noise` (fp32 [B, V]) when given, else drawn in-kernel from
  * (seed, b, v).  Evaluated as argmax_v (logits/T - log noise), which has the same
  * maximiser.  T[b] == 0 takes argmax(logits[b]) (greedy extension).  Ties resolve
- * to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V. */
+ * to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V.
+ * Without `noise` the draw uses the inverse CDF of softmax(logits/T) with one uniform per row from (seed, b):
+ * the same distribution as the noisy argmax at one exp per logit instead of a hash and two logs. */
 size_t nv_sample_workspace_bytes(int B);
 int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
               int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,

@@ -382,6 +382,30 @@ def test_sampler_large_vocab_greedy_and_distribution():
     assert abs((toks == 3).float().mean().item() - 0.75) < 0.04
 
 
+@pytest.mark.parametrize("V", [20000, 20003])
+@pytest.mark.parametrize("temp", [1.0, 0.5])
+def test_sampler_in_kernel_randomness_follows_softmax(V, temp):
+    """Without injected noise the sampler draws from softmax(logits / T) (inverse CDF over slice sums): candidates
+    spread over all slices of the row come out at their softmax rates; V % 8 != 0 takes the unaligned path."""
+    from byox_vllm_amd import kernels
+    B = 8000
+    idx = [3, 2500, 7000, 9999, 12001, 15000, 17500, V - 1]
+    p = np.array([0.30, 0.20, 0.15, 0.10, 0.10, 0.07, 0.05, 0.03])
+    row = torch.full((V,), -40.0)
+    row[idx] = torch.from_numpy(np.log(p)).float()
+    logits = row.to(torch.bfloat16).unsqueeze(0).expand(B, V).contiguous()
+    want = torch.softmax(logits[0].float() / temp, dim=-1)[idx].numpy()
+    toks = kernels.sample(dev(logits), dev(torch.full((B,), temp)), seed=123).cpu().numpy()
+    assert set(toks.tolist()) <= set(idx)
+    freq = np.array([(toks == i).mean() for i in idx])
+    assert np.abs(freq - want).max() < 0.02, (freq, want)
+    # another seed gives other draws; greedy rows in the same launch are exact
+    temps = torch.full((B,), temp)
+    temps[::2] = 0.0
+    toks2 = kernels.sample(dev(logits), dev(temps), seed=124).cpu().numpy()
+    assert (toks2[::2] == 3).all() and (toks2[1::2] != toks[1::2]).any()
+
+
 def test_stage_decode_inputs_pads_like_reference():
     from byox_vllm_amd import kernels
     bs, padded, cols, gcols = 3, 8, 2, 5
