@@ -163,6 +163,9 @@ ATTN_TOL = {"bf16": 2e-2, "fp16": 3e-3}   # |O| <= ~4 here; P is rounded to the 
     dict(B=4, H=16, Hkv=8, D=128, bs=32, lens=[31, 32, 33, 64]),            # Qwen3-0.6B heads
     dict(B=2, H=4, Hkv=4, D=64, bs=16, lens=[5, 48]),                       # MHA (group of 1)
     dict(B=3, H=14, Hkv=2, D=64, bs=16, lens=[0, 40, 0]),                   # graph padding rows (context 0)
+    dict(B=7, H=14, Hkv=2, D=64, bs=256, lens=[1023, 1024, 1025, 1061, 2047, 3000, 33]),   # bench-sized contexts:
+    dict(B=4, H=28, Hkv=4, D=128, bs=256, lens=[1024, 1057, 2049, 31]),     # every wavefront runs its chunk rotation
+    dict(B=2, H=8, Hkv=2, D=128, bs=16, lens=[515, 258]),                   # zero-padded query slots (group 4 of 16)
 ])
 @pytest.mark.parametrize("splits", [1, 2, 5])
 def test_paged_decode_attention(name, cfg, splits):
