@@ -300,13 +300,17 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   }
   __syncthreads();
 
-  // ---- add the second k-step group's accumulators into the first's, through LDS (two passes)
+  // ---- join the two k-step groups' accumulators through LDS, half of the tiles per pass.  In the first pass
+  // group 1 hands its half to group 0; in the second the direction is reversed, so each group ends up owning the
+  // finished sums of one half of the tiles and both run the epilogue (the RoPE epilogue needs whole rows in one
+  // place: there group 0 takes both halves).  a + b == b + a bit for bit, so the owner does not change the result.
   {
     f32x4* red = reinterpret_cast<f32x4*>(lds_raw);   // [RED_REGS][256 threads of the column group]
     const int t4 = tid & 255;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      if (kg == 1) {
+      const int giver = (EPI == 3 || pass == 0) ? 1 : 0;
+      if (kg == giver) {
 #pragma unroll
         for (int r = 0; r < RED_REGS; ++r) {
           const int idx = pass * RED_REGS + r;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
         }
       }
       __syncthreads();
-      if (kg == 0) {
+      if (kg != giver) {
 #pragma unroll
         for (int r = 0; r < RED_REGS; ++r) {
           const int idx = pass * RED_REGS + r;
@@ -324,7 +328,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       __syncthreads();
     }
   }
-  if (kg == 1) return;
+  if (EPI == 3 && kg == 1) return;
+  // tile idx = j * TM + i is finished by group 0 if it travelled in the first pass, else by group 1
+  auto owns = [&](int idx) { return EPI == 3 || ((idx < RED_REGS) == (kg == 0)); };
 
   // ---- RoPE epilogue: the workgroup's 64 NTW columns are exactly one head (blockIdx.x = head slot).  The rotation
   // pairs element d with d + D/2, which live in different wavefronts, so the finished rows (+bias, rounded to the
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + 16 * i + c;
-        if (m < M) {
+        if (m < M && owns(j * TM + i)) {
           u32x2 o;
           o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
           o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + 16 * i + c;
-        if (m < M) {
+        if (m < M && owns(j * TM + i)) {
           float r[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + 16 * i + c;
-        if (m < M) *reinterpret_cast<f32x4*>(slab + m * N + nb) = acc[j][i];
+        if (m < M && owns(j * TM + i)) *reinterpret_cast<f32x4*>(slab + m * N + nb) = acc[j][i];
       }
     }
   }
