@@ -175,7 +175,8 @@ class ModelRunner:
             self._dev_stage[:n + 2].copy_(self._host_stage[:n + 2], non_blocking=True)
             kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
         self._replay(padded)
-        return g["tokens"][:bs].tolist()
+        torch.cuda.current_stream().synchronize()
+        return self._host_tokens_np[:bs].tolist()
 
     def _pack_decode(self, seqs: list[Sequence], host: np.ndarray) -> tuple[int, int]:
         """Fill ``host`` (int32) with one decode step's integers, laid out as nv_stage_decode_packed reads them:
@@ -393,6 +394,8 @@ class ModelRunner:
         self._host_stage = torch.zeros(stage_words, dtype=torch.int32, device="cpu").pin_memory()
         self._host_stage_np = self._host_stage.numpy()
         self._dev_stage = torch.zeros(stage_words, dtype=torch.int32, device=dev)
+        self._host_tokens = torch.zeros(max_bs, dtype=torch.int64, device="cpu").pin_memory()
+        self._host_tokens_np = self._host_tokens.numpy()
         self.graph_has_head = self.world_size == 1
         self.graph_bs = sorted(config.graph_batch_sizes) if config.graph_batch_sizes else graph_batch_sizes(max_bs)
         max_bs = self.graph_bs[-1]
@@ -418,6 +421,8 @@ class ModelRunner:
                 logits = self.model.compute_logits(hidden)
                 kernels.sample(logits, g["temperatures"][lo:hi], seed=self.config.seed + 7919 * k,
                                seed_offset=g["step"], out=g["tokens"][lo:hi])
+                # the graph ends by delivering the tokens to pinned host memory: the host then only waits for the stream
+                self._host_tokens[lo:hi].copy_(g["tokens"][lo:hi], non_blocking=True)
 
         # One graph per micro-batch.  A hipGraph replays its nodes on a single hardware queue even when it was
         # captured from several streams, so parallelism between micro-batches comes from replaying their
