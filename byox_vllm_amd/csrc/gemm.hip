@@ -75,6 +75,7 @@ static double plan_cost(int64_t M, int N, int K, int wfmt, int ntw, int split_k,
   const int kb_per_block = (nkb + split_k - 1) / split_k;
   double us = rounds * (kb_per_block * t_kb + (paired ? 3.0 : 4.0));
   if (slabs) us += 2.0 * split_k * (double)M * N * 4.0 / 4.0e6;   // slab bytes at ~4 TB/s, written and read once
+  if (slabs && split_k > 8) us += 1.0;   // the consumer sums slabs in batches of 8 loads: a ninth costs it a round trip
   return us;
 }
 
