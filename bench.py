@@ -269,7 +269,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic (random weights, random KV history, random prompts)",
-            "config": {"workload": args.workload, "model": model_name, "weight_format": quantization or dtype_name,
+            "config": {"workload": args.workload, "geometry": model_name, "weight_format": quantization or dtype_name,
                        "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
                        "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": not args.eager,
                        "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
