@@ -74,7 +74,7 @@ class StepDriver:
             tokens = t.tolist()
         for seq, tok in zip(self.seqs, tokens):
             seq.append_token(tok)
-            if len(seq) % seq.block_size == 1:
+            if seq.num_tokens % seq.block_size == 1:
                 seq.block_table.append(self.next_block)
                 self.next_block += 1
 

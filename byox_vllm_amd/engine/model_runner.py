@@ -189,17 +189,23 @@ class ModelRunner:
         lens = list(map(len, tables_in))
         cols, total = max(lens), sum(lens)
         n = 5 * bs + bs * cols
-        ntok = np.array([seq.num_tokens for seq in seqs], dtype=np.int32)
-        host[0:bs] = [seq.last_token for seq in seqs]
-        host[bs:2 * bs] = ntok - 1
-        host[2 * bs:3 * bs] = np.array([t[-1] for t in tables_in], dtype=np.int32) * block + (ntok - 1) % block
-        host[3 * bs:4 * bs] = ntok
-        host[4 * bs:5 * bs].view(np.float32)[:] = [seq.temperature for seq in seqs]
+        head = host[:4 * bs].reshape(4, bs)
+        head[0] = [seq.last_token for seq in seqs]
+        ntok = head[3]
+        ntok[:] = [seq.num_tokens for seq in seqs]
+        np.subtract(ntok, 1, out=head[1])
+        # Steady-state decode presents the same Sequence objects step after step: what cannot change for a given
+        # object (its temperature) and what rarely changes (the padded tables, the last block of every row) is kept
+        # from the previous step.  List equality short-cuts on identity, so the checks cost well under a microsecond.
+        cached = getattr(self, "_pack_cache", None)
+        if cached is None or cached["seqs"] != seqs:
+            cached = self._pack_cache = {"seqs": list(seqs), "key": None,
+                                         "temps": np.array([seq.temperature for seq in seqs], dtype=np.float32)}
+        host[4 * bs:5 * bs].view(np.float32)[:] = cached["temps"]
         tables = host[5 * bs:n].reshape(bs, cols)
-        key = (tuple(map(id, tables_in)), total, cols, Sequence.table_epoch)
-        cached = getattr(self, "_table_cache", None)
-        if cached is not None and cached[0] == key:
-            tables[:] = cached[1]
+        key = (total, cols, Sequence.table_epoch)
+        if cached["key"] == key and cached["tables_in"] == tables_in:
+            tables[:] = cached["tables"]
         else:
             if total == bs * cols:
                 tables[:] = tables_in
@@ -207,7 +213,9 @@ class ModelRunner:
                 tables.fill(-1)
                 for i, t in enumerate(tables_in):
                     tables[i, : len(t)] = t
-            self._table_cache = (key, tables.copy())
+            cached["key"], cached["tables_in"], cached["tables"] = key, tables_in, tables.copy()
+            cached["last_block_row"] = np.array([t[-1] for t in tables_in], dtype=np.int32) * block
+        np.add(cached["last_block_row"], head[1] % block, out=head[2])
         return n, cols
 
     def _prepare_step(self, seqs, is_prefill) -> dict:

@@ -297,3 +297,5 @@ def test_pack_decode_matches_prepare_functions_and_tracks_table_changes():
     check()
     seqs.pop()                               # batch composition changes
     check()
+    seqs.reverse()                           # same size, other rows: per-row temperatures must follow
+    check()
