@@ -58,6 +58,30 @@ __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  if constexpr (!TAIL) {
+    // wave-uniform 64-bit row bases plus one 32-bit per-lane byte offset for K and one for V: the loads take the
+    // scalar-base form and the addresses of a whole chunk cost two vector registers instead of two per load
+    const uint32_t koff = (uint32_t)(c * (int)row_stride + 8 * g) * 2u;
+    const uint32_t voff = (uint32_t)(4 * g * (int)row_stride + NM * c) * 2u;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const char* kb = reinterpret_cast<const char*>(k_base + rows[tl] * row_stride);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) r.kf[tl][ks] = *reinterpret_cast<const frag_t*>(kb + (koff + 64u * ks));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* vb = reinterpret_cast<const char*>(v_base + (rows[j >> 2] + (j & 3)) * row_stride);
+      if constexpr (NM == 8) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(vb + voff);
+        r.vv[j][0] = t[0]; r.vv[j][1] = t[1]; r.vv[j][2] = t[2]; r.vv[j][3] = t[3];
+      } else {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(vb + voff);
+        r.vv[j][0] = t[0]; r.vv[j][1] = t[1];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl) {
     int64_t krow = rows[tl] + c;
@@ -246,9 +270,15 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
     if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, r, qf, base, n_keys, n_keys, scale2);
     else chunk_compute<T, D, true>(st, r, qf, base, n_keys, n_keys, scale2);
   };
+  // a chunk that has a successor in this wavefront's sequence is not the sequence's last chunk, so all of its 32
+  // keys exist: the steady-state loop body carries no masking code
+  auto compute_full = [&](ChunkRegs<T, D>& r, int chunk) {
+    chunk_compute<T, D, false>(st, r, qf, chunk << 5, n_keys, n_keys, scale2);
+  };
   if constexpr (D > 64) {
-    // 128-wide heads: two chunks in flight plus the accumulators do not fit 256 registers, so one register set is
-    // loaded ahead and handed over by copy (the 16 KB chunks keep enough bytes in flight per wavefront regardless)
+    // 128-wide heads: with two alternating register sets the unrolled loop needs more than 256 registers (it spills
+    // and runs 13 % slower), so one set is loaded ahead and handed over by copy (the 16 KB chunks keep enough bytes
+    // in flight per wavefront regardless)
     int64_t rows_cur[2], rows_nxt[2] = {0, 0};
     lookup(ch, rows_cur);
     if (ch < n_chunks) {
@@ -259,8 +289,12 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
         const bool has_next = ch + step < n_chunks;
         int64_t rows_nn[2] = {0, 0};
         if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
-        if (has_next) chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
-        compute(cur, ch);
+        if (has_next) {
+          chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
+          compute_full(cur, ch);
+        } else {
+          compute(cur, ch);
+        }
         cur = nxt;
         rows_nxt[0] = rows_nn[0];
         rows_nxt[1] = rows_nn[1];
@@ -280,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
         }
         lookup(ch + 2 * step, rows_a);
         chunk_load<T, D, false>(rb, k_base, v_base, row_stride, rows_b, INT64_MAX);
-        compute(ra, ch);
+        compute_full(ra, ch);
         ch += step;
         if (ch + step >= n_chunks) {
           compute(rb, ch);
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
         }
         lookup(ch + 2 * step, rows_b);
         chunk_load<T, D, false>(ra, k_base, v_base, row_stride, rows_a, INT64_MAX);
-        compute(rb, ch);
+        compute_full(rb, ch);
         ch += step;
       }
     }

@@ -51,6 +51,11 @@ if __name__ == "__main__":
         run("gate_up", M, 37888, 3584, "w4a16", 4, silu=True)
         run("down", M, 3584, 18944, "w4a16", 4, partial=True)
         run("lm_head", M, 152064, 3584, None, 2)
+    elif which == "7bcold":   # enough copies that no weight is still in the 256 MB Infinity Cache when it is read again
+        run("qkv", M, 4608, 3584, "w4a16", 80, partial=True)
+        run("o", M, 3584, 3584, "w4a16", 100, partial=True)
+        run("gate_up", M, 37888, 3584, "w4a16", 10, silu=True)
+        run("down", M, 3584, 18944, "w4a16", 20, partial=True)
     elif which == "sweep7b":
         for sk in (2, 3, 4, 6, 9):
             run("down", M, 3584, 18944, "w4a16", 4, split_k=sk, partial=True)
