@@ -106,13 +106,13 @@ __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k
   }
 }
 
-// The two MFMA products and the online softmax for one loaded chunk.
-//  limit: number of visible keys for this lane's column; base: first token of the chunk;
-//  n_keys: keys at or past it may hold junk (TAIL zeroes their V rows).
-template <typename T, int D, bool TAIL>
-__device__ __forceinline__ void chunk_compute(AttnState<T, D>& st, ChunkRegs<T, D>& r,
-                                              const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS], int base, int limit,
-                                              int n_keys, float scale2) {
+// One loaded chunk against one 16-column query tile, in three steps so that several query tiles can share the
+// chunk's registers: scores + online softmax (per tile), V^T operands (once per chunk), P.V (per tile).
+//  limit: number of visible keys for this lane's column; base: first token of the chunk.
+template <typename T, int D>
+__device__ __forceinline__ typename VecOf<T>::x8 chunk_scores(AttnState<T, D>& st, const ChunkRegs<T, D>& r,
+                                                              const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS],
+                                                              int base, int limit, float scale2) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, g = lane >> 4;
@@ -157,9 +157,58 @@ __device__ __forceinline__ void chunk_compute(AttnState<T, D>& st, ChunkRegs<T, 
   st.l = st.l * alpha + psum;
 #pragma unroll
   for (int m = 0; m < NM; ++m) st.acc[m] *= alpha;
+  return pf;
+}
 
-  // ---- V^T operand: 8 x NM transpose of 16-bit values held in registers
+// V^T operands of a chunk: 8 x NM transpose of 16-bit values held in registers.  n_keys: keys at or past it may
+// hold junk (TAIL zeroes their V rows).
+template <typename T, int D, bool TAIL>
+__device__ __forceinline__ void chunk_v_operands(ChunkRegs<T, D>& r, int base, int n_keys,
+                                                 typename VecOf<T>::x8 (&vt)[AttnGeom<D>::NM]) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int NM = AttnGeom<D>::NM;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
   if (TAIL) {  // keys past the end may hold anything (even NaN bit patterns): zero them, 0 * NaN != 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tok = base + ((j < 4) ? (4 * g + j) : (16 + 4 * g + j - 4));
+      if (tok >= n_keys) {
+#pragma unroll
+        for (int e = 0; e < NM / 2; ++e) r.vv[j][e] = 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    u32x4 w;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const uint32_t a = r.vv[2 * jj][m >> 1], b = r.vv[2 * jj + 1][m >> 1];
+      w[jj] = (m & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    vt[m] = __builtin_bit_cast(frag_t, w);
+  }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void chunk_pv(AttnState<T, D>& st, const typename VecOf<T>::x8 (&vt)[AttnGeom<D>::NM],
+                                         typename VecOf<T>::x8 pf) {
+#pragma unroll
+  for (int m = 0; m < AttnGeom<D>::NM; ++m) st.acc[m] = mfma16(vt[m], pf, st.acc[m]);
+}
+
+// The two MFMA products and the online softmax for one loaded chunk and one query tile.
+template <typename T, int D, bool TAIL>
+__device__ __forceinline__ void chunk_compute(AttnState<T, D>& st, ChunkRegs<T, D>& r,
+                                              const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS], int base, int limit,
+                                              int n_keys, float scale2) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int NM = AttnGeom<D>::NM;
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const frag_t pf = chunk_scores<T, D>(st, r, qf, base, limit, scale2);
+  // same arithmetic as chunk_v_operands + chunk_pv, but each V^T fragment is built right before its MFMA: with a
+  // single query tile that keeps eight fewer fragments alive
+  if (TAIL) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tok = base + ((j < 4) ? (4 * g + j) : (16 + 4 * g + j - 4));
@@ -425,9 +474,12 @@ __global__ __launch_bounds__(256) void decode_combine_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ prefill
-// grid (ceil(max_seqlen_q / 64), H, num_seqs); wavefront w of a workgroup owns
-// query tokens [64*bx + 16*w, +16) of one head of one sequence.
-template <typename T, int D, bool PAGED>
+// grid (ceil(max_seqlen_q / (64 QT)), H, num_seqs); wavefront w of a workgroup owns QT consecutive 16-query tiles
+// of one head of one sequence.  Every K/V chunk it loads is multiplied against all QT tiles, so the bytes fetched per
+// flop fall with QT (the chunk's V^T operands are also built once instead of once per tile); the loads of the next
+// chunk are issued before the MFMAs of the current one (two register sets in alternation, PP).  Workgroups are
+// numbered from the end of the sequence backwards: late query tiles see the most keys and start first.
+template <typename T, int D, bool PAGED, int QT, bool PP>
 __global__ __launch_bounds__(256) void prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
@@ -436,35 +488,43 @@ __global__ __launch_bounds__(256) void prefill_kernel(
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int seq = blockIdx.z, head = blockIdx.y;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q0 = cu_q[seq], q_len = cu_q[seq + 1] - q0;
   const int k0 = cu_k[seq], k_len = cu_k[seq + 1] - k0;
-  const int qt = blockIdx.x * 64 + wid * 16;   // first query of this wavefront's tile
+  const int bx = gridDim.x - 1 - blockIdx.x;
+  const int qt = (bx * 4 + wid) * (16 * QT);   // first query of this wavefront
   if (qt >= q_len) return;
   const int kvh = head / (H / Hkv);
-  const int qi = qt + c;
-  const bool live = qi < q_len;
-  // bottom-right aligned causal mask: query qi sees keys [0, k_len - q_len + qi]
-  const int limit = live ? (k_len - q_len + qi + 1) : 0;
-  int last_q = qt + 15;
-  if (last_q > q_len - 1) last_q = q_len - 1;
-  const int n_keys = k_len - q_len + last_q + 1;   // keys any column of the tile can see
 
-  frag_t qf[KS];
-  {
-    const uint16_t* qr = q + (int64_t)(q0 + (live ? qi : qt)) * q_stride + (int64_t)head * D + 8 * g;
+  // bottom-right aligned causal mask: query qi sees keys [0, k_len - q_len + qi]
+  int limit[QT], tile_keys[QT];
+  bool live[QT];
+  frag_t qf[QT][KS];
+  AttnState<T, D> st[QT];
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    const int t0 = qt + 16 * i, qi = t0 + c;
+    live[i] = qi < q_len;
+    limit[i] = live[i] ? (k_len - q_len + qi + 1) : 0;
+    int last_q = t0 + 15;
+    if (last_q > q_len - 1) last_q = q_len - 1;
+    tile_keys[i] = t0 < q_len ? (k_len - q_len + last_q + 1) : 0;   // keys any column of the tile can see
+    const uint16_t* qr = q + (int64_t)(q0 + (live[i] ? qi : qt)) * q_stride + (int64_t)head * D + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 t = *reinterpret_cast<const u32x4*>(qr + 32 * ks);
-      if (!live) t = u32x4{0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(frag_t, t);
+      if (!live[i]) t = u32x4{0, 0, 0, 0};
+      qf[i][ks] = __builtin_bit_cast(frag_t, t);
     }
-  }
-  AttnState<T, D> st;
-  st.m = -INFINITY;
-  st.l = 0.f;
+    st[i].m = -INFINITY;
+    st[i].l = 0.f;
 #pragma unroll
-  for (int m = 0; m < NM; ++m) st.acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NM; ++m) st[i].acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int n_keys = 0;   // keys the wavefront's last existing tile can see: the extent of its chunk loop
+#pragma unroll
+  for (int i = 0; i < QT; ++i) n_keys = tile_keys[i] > n_keys ? tile_keys[i] : n_keys;
 
   const int64_t row_stride = PAGED ? (int64_t)Hkv * D : kv_stride;
   const uint16_t* k_base = k + (int64_t)kvh * D;
@@ -472,7 +532,9 @@ __global__ __launch_bounds__(256) void prefill_kernel(
   const int32_t* bt_row = PAGED ? block_tables + (int64_t)seq * bt_stride : nullptr;
   const int64_t max_row = PAGED ? INT64_MAX : (int64_t)k0 + k_len - 1;
   const int n_chunks = (n_keys + 31) >> 5;
-  for (int ch = 0; ch < n_chunks; ++ch) {
+
+  // a chunk that ends past n_keys takes the TAIL forms: rows clamped (packed keys end with the buffer), junk V zeroed
+  auto load = [&](ChunkRegs<T, D>& r, int ch) {
     const int base = ch << 5;
     int64_t rows[2];
     if (PAGED) {
@@ -482,31 +544,71 @@ __global__ __launch_bounds__(256) void prefill_kernel(
       rows[0] = k0 + base;
       rows[1] = k0 + base + 16;
     }
-    // the causal diagonal is masked per token in both variants; TAIL additionally clamps rows and zeroes junk V
-    if (base + 32 <= n_keys)
-      attn_chunk<T, D, false>(st, qf, k_base, v_base, row_stride, rows, max_row, base, limit, n_keys, scale2);
-    else
-      attn_chunk<T, D, true>(st, qf, k_base, v_base, row_stride, rows, max_row, base, limit, n_keys, scale2);
+    if (base + 32 <= n_keys) chunk_load<T, D, false>(r, k_base, v_base, row_stride, rows, max_row);
+    else chunk_load<T, D, true>(r, k_base, v_base, row_stride, rows, max_row);
+  };
+  auto compute = [&](ChunkRegs<T, D>& r, int ch) {
+    const int base = ch << 5;
+    frag_t pf[QT], vt[NM];
+#pragma unroll
+    for (int i = 0; i < QT; ++i)   // tiles that end before this chunk skip it (wave-uniform)
+      if (base < tile_keys[i]) pf[i] = chunk_scores<T, D>(st[i], r, qf[i], base, limit[i], scale2);
+    if (base + 32 <= n_keys) chunk_v_operands<T, D, false>(r, base, n_keys, vt);
+    else chunk_v_operands<T, D, true>(r, base, n_keys, vt);
+#pragma unroll
+    for (int i = 0; i < QT; ++i)
+      if (base < tile_keys[i]) chunk_pv<T, D>(st[i], vt, pf[i]);
+  };
+  if constexpr (PP) {
+    ChunkRegs<T, D> ra, rb;
+    load(ra, 0);
+    int ch = 0;
+    while (true) {
+      if (ch + 1 >= n_chunks) {
+        compute(ra, ch);
+        break;
+      }
+      load(rb, ch + 1);
+      compute(ra, ch);
+      ++ch;
+      if (ch + 1 >= n_chunks) {
+        compute(rb, ch);
+        break;
+      }
+      load(ra, ch + 1);
+      compute(rb, ch);
+      ++ch;
+    }
+  } else {
+    for (int ch = 0; ch < n_chunks; ++ch) {
+      ChunkRegs<T, D> r;
+      load(r, ch);
+      compute(r, ch);
+    }
   }
-  float l = st.l;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  if (!live) return;
-  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
-  uint16_t* orow = out + (int64_t)(q0 + qi) * out_stride + (int64_t)head * D;
+
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    uint16_t* dst = orow + NM * (4 * g + r);
-    if constexpr (NM == 8) {
-      u32x4 w;
+  for (int i = 0; i < QT; ++i) {
+    float l = st[i].l;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (!live[i]) continue;
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    uint16_t* orow = out + (int64_t)(q0 + qt + 16 * i + c) * out_stride + (int64_t)head * D;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = pack2<T>(st.acc[2 * e][r] * inv, st.acc[2 * e + 1][r] * inv);
-      *reinterpret_cast<u32x4*>(dst) = w;
-    } else {
-      u32x2 w;
+    for (int r = 0; r < 4; ++r) {
+      uint16_t* dst = orow + NM * (4 * g + r);
+      if constexpr (NM == 8) {
+        u32x4 w;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) w[e] = pack2<T>(st.acc[2 * e][r] * inv, st.acc[2 * e + 1][r] * inv);
-      *reinterpret_cast<u32x2*>(dst) = w;
+        for (int e = 0; e < 4; ++e) w[e] = pack2<T>(st[i].acc[2 * e][r] * inv, st[i].acc[2 * e + 1][r] * inv);
+        *reinterpret_cast<u32x4*>(dst) = w;
+      } else {
+        u32x2 w;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) w[e] = pack2<T>(st[i].acc[2 * e][r] * inv, st[i].acc[2 * e + 1][r] * inv);
+        *reinterpret_cast<u32x2*>(dst) = w;
+      }
     }
   }
 }
@@ -612,12 +714,25 @@ extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* 
   if (num_seqs == 0 || max_seqlen_q <= 0) return NV_OK;
   const float scale2 = scale * LOG2E;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((max_seqlen_q + 63) / 64, H, num_seqs), block(256);
-#define LAUNCH_PRE(TT, DD, PP)                                                                                        \
-  prefill_kernel<TT, DD, PP><<<grid, block, 0, s>>>((const uint16_t*)q, q_row_stride, (const uint16_t*)k,            \
-                                                    (const uint16_t*)v, kv_row_stride, cu_seqlens_q, cu_seqlens_k,   \
-                                                    block_tables, bt_stride, (uint16_t*)out, out_row_stride, H, Hkv, \
-                                                    block_size, scale2)
+  // Query tiles per wavefront.  Measured (8 x 1024 tokens, 14/2 heads, D=64): one tile without prefetch 161 us, one
+  // tile with prefetch 168, two tiles with prefetch 126, four tiles 155 (400 registers: one wavefront per SIMD).
+  // At D=128 two tiles leave no room for the second register set and lose at long sequences, so that width keeps
+  // one tile and no prefetch.
+  int qtiles = (D == 64 && max_seqlen_q > 64) ? 2 : 1;
+  if (const char* e = getenv("NV_PREFILL_QT")) {   // testing aid: forces the tile count
+    const int f = atoi(e);
+    if (f == 1 || (f == 2 && D == 64)) qtiles = f;
+  }
+  dim3 grid((max_seqlen_q + 64 * qtiles - 1) / (64 * qtiles), H, num_seqs), block(256);
+#define LAUNCH_PRE_Q(TT, DD, PP, QQ, PING)                                                                            \
+  prefill_kernel<TT, DD, PP, QQ, PING><<<grid, block, 0, s>>>(                                                        \
+      (const uint16_t*)q, q_row_stride, (const uint16_t*)k, (const uint16_t*)v, kv_row_stride, cu_seqlens_q,          \
+      cu_seqlens_k, block_tables, bt_stride, (uint16_t*)out, out_row_stride, H, Hkv, block_size, scale2)
+#define LAUNCH_PRE(TT, DD, PP)                                                  \
+  do {                                                                          \
+    if (DD == 64 && qtiles == 2) LAUNCH_PRE_Q(TT, 64, PP, 2, true);             \
+    else LAUNCH_PRE_Q(TT, DD, PP, 1, false);                                    \
+  } while (0)
   const bool paged = block_tables != nullptr;
   if (dtype == NV_BF16) {
     if (D == 128) { if (paged) LAUNCH_PRE(bf16_t, 128, true); else LAUNCH_PRE(bf16_t, 128, false); }
@@ -626,6 +741,7 @@ extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* 
     if (D == 128) { if (paged) LAUNCH_PRE(f16_t, 128, true); else LAUNCH_PRE(f16_t, 128, false); }
     else          { if (paged) LAUNCH_PRE(f16_t, 64, true); else LAUNCH_PRE(f16_t, 64, false); }
   }
+#undef LAUNCH_PRE_Q
 #undef LAUNCH_PRE
   NV_CHECK_LAUNCH();
   return NV_OK;

@@ -32,6 +32,29 @@ def run(B, H, Hkv, D, S, L, splits_list, bs=256, dt=torch.bfloat16):
         print(f"B={B} H={H}/{Hkv} D={D} S={S} waves={os.environ.get('NV_ATTN_WAVES','auto')} splits={splits}: "
               f"{us:7.2f} us/launch  {bytes_per / us / 1e6:6.2f} TB/s", flush=True)
 
+def run_prefill(n, S, H, Hkv, D, dt=torch.bfloat16):
+    """Causal varlen prefill attention on n packed sequences of S tokens."""
+    dev = "cuda"
+    T = n * S
+    q = torch.randn(T, H, D, device=dev, dtype=dt)
+    k = torch.randn(T, Hkv, D, device=dev, dtype=dt)
+    v = torch.randn(T, Hkv, D, device=dev, dtype=dt)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+    call = lambda: kernels.attn_prefill(q, k, v, cu, cu, S, D ** -0.5, out=out)
+    call(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    a.record()
+    for _ in range(reps):
+        call()
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / reps
+    flops = 4.0 * n * (S * (S + 1) / 2) * H * D
+    print(f"prefill n={n} S={S} H={H}/{Hkv} D={D} qt={os.environ.get('NV_PREFILL_QT', 'auto')}: {us:8.1f} us  "
+          f"{flops / us / 1e6:6.1f} TFLOP/s (causal flops)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "0.5b"
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -39,6 +62,12 @@ if __name__ == "__main__":
         run(128, 14, 2, 64, S, 24, [1, 2, 4])
     elif which == "7b":
         run(128, 28, 4, 128, S, 8, [1, 2])
+    elif which == "prefill":
+        run_prefill(8, 1024, 14, 2, 64)
+        run_prefill(2, 4096, 14, 2, 64)
+        run_prefill(8, 1024, 28, 4, 128)
+        run_prefill(2, 4096, 28, 4, 128)
+        run_prefill(64, 128, 14, 2, 64)
     elif which == "small":
         run(32, 14, 2, 64, 1024, 24, [1, 2, 4, 8])
         run(1, 14, 2, 64, 1024, 24, [1, 4, 8, 16])

@@ -230,6 +230,30 @@ def test_prefill_attention_packed(name, cfg):
     assert err <= ATTN_TOL[name], err
 
 
+@pytest.mark.parametrize("qt", ["1", "2"])
+@pytest.mark.parametrize("cfg", [
+    dict(H=14, Hkv=2, D=64, lens=[300, 97, 257, 128]),     # several query tiles per wavefront, ragged ends
+    dict(H=8, Hkv=4, D=128, lens=[200, 65]),
+])
+def test_prefill_attention_query_tiles_per_wavefront(cfg, qt, monkeypatch):
+    """The prefill kernel's tiling choices (one or two 16-query tiles per wavefront, prefetch on or off) are all the
+    same function: forced either way, long ragged sequences match the oracle."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_PREFILL_QT", qt)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    T = sum(cfg["lens"])
+    H, Hkv, D = cfg["H"], cfg["Hkv"], cfg["D"]
+    q = torch.randn(T, H, D, generator=g).to(dt)
+    k = torch.randn(T, Hkv, D, generator=g).to(dt)
+    v = torch.randn(T, Hkv, D, generator=g).to(dt)
+    cu = torch.tensor([0] + list(np.cumsum(cfg["lens"])), dtype=torch.int32)
+    want = OA.attn_varlen(q, k, v, cu, cu, D ** -0.5)
+    got = kernels.attn_prefill(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(cfg["lens"]), D ** -0.5)
+    err = (got.float().cpu() - want.float()).abs().max().item()
+    assert err <= ATTN_TOL["bf16"], err
+
+
 def test_prefill_attention_prefix_cache_paged():
     """seqlen_q < seqlen_k: keys come from the paged cache, mask aligned to the bottom-right corner."""
     from byox_vllm_amd import kernels
