@@ -30,6 +30,14 @@
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
+// Query tiles (of 16) per wavefront in the LDS-fed prefill kernel.  One tile keeps two workgroups per CU (~185
+// registers); two tiles halve the LDS reads per flop but run one workgroup per CU and measured 20-35 % slower.
+#ifndef NV_PREFILL_QT64
+#define NV_PREFILL_QT64 1
+#endif
+#ifndef NV_PREFILL_QT128
+#define NV_PREFILL_QT128 1
+#endif
 
 template <int D> struct AttnGeom {
   static constexpr int KS = D / 32;   // k-steps of the S^T product
@@ -613,6 +621,291 @@ __global__ __launch_bounds__(256) void prefill_kernel(
   }
 }
 
+// ------------------------------------------------------------------ prefill, K/V shared through LDS
+// One workgroup = 4 wavefronts = HW query heads of one KV head x (4 / HW) groups of 16 QT queries, so every K/V
+// byte the workgroup fetches serves all four wavefronts (the register-fed kernel above fetches it once per
+// wavefront).  Keys are taken in blocks of NC chunks of 32 (128 keys at D = 64, 64 at D = 128) and the online
+// softmax advances once per block: its fixed cost per step (column maximum across lanes, rescaling the output
+// accumulators, -inf guards) is what bounded the chunk-at-a-time form at ~20 VALU instructions per score.
+// A block travels L2 -> LDS by LDS-DMA, 1 KiB per wave-instruction, into one half of a double buffer while the other
+// half is multiplied.  The DMA writes its 64 lanes' 16-byte pieces to consecutive LDS addresses, so the LDS image is
+// shaped by choosing which global piece each lane fetches:
+//   K piece (tile tl, k-step ks): lane (c, g) fetches K[16 tl + c][32 ks + 8 g ..+7] - exactly the MFMA A fragment,
+//     read back with one conflict-free ds_read_b128 at lane * 16;
+//   V piece: 8 rows x 128 B (D = 64) or 4 rows x 256 B (D = 128), rows whole but with their 16-byte pieces XOR-ed
+//     by a function of the row, read back with ds_read_b64_tr_b16: the hardware hands lane c of a 16-lane group the
+//     c-th column of a 4-token x 16-d block, i.e. the V^T A-fragment of the P.V product with no transpose on the
+//     VALU (MFMA m covers d = 16 m .. 16 m + 15; the XOR spreads the 8 rows a 32-lane half touches over all banks).
+// One barrier per block: at the top of iteration i the wavefront waits for its own pieces of block i, the barrier
+// then says that all of block i has landed AND that everybody is done with block i-1, whose half the DMA of block
+// i+1 may now overwrite.  Every block is fetched whole (rows past the sequence are clamped to real ones), so LDS never
+// holds uninitialised values for a token below k_len.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void global_void_t;
+
+// Online-softmax step of one 16-query tile over a block of NC chunks whose raw scores sit in s[NC][2].
+// MASK: apply the causal limit (only blocks that touch the tile's diagonal need it).  Returns P^T fragments.
+template <typename T, int D, int NC, bool MASK>
+__device__ __forceinline__ void block_softmax(AttnState<T, D>& st, f32x4 (&s)[NC][2], int base, int limit, float scale2,
+                                              typename VecOf<T>::x8 (&pf)[NC]) {
+  constexpr int NM = AttnGeom<D>::NM;
+  const int g = (threadIdx.x & 63) >> 4;
+  float cmax = -INFINITY;
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        if (MASK) {
+          const int tok = base + 32 * cc + 16 * tl + 4 * g + rr;
+          s[cc][tl][rr] = (tok < limit) ? s[cc][tl][rr] : -INFINITY;
+        }
+        cmax = fmaxf(cmax, s[cc][tl][rr]);
+      }
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+  // scale2 > 0, so the maximum of the scaled scores is the scaled maximum: the scale rides in the exponent's fma
+  const float m_new = fmaxf(st.m, cmax * scale2);
+  const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+  const float alpha = (st.m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st.m - m_use);
+  float psum = 0.f;
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[cc][tl][rr], scale2, -m_use));
+        psum += p;
+        pf[cc][tl * 4 + rr] = (T)p;
+      }
+  st.m = m_new;
+  st.l = st.l * alpha + psum;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) st.acc[m] *= alpha;
+}
+
+// XOR applied to the 16-byte piece index of row t of a chunk's V image (see above)
+template <int D> __device__ __forceinline__ int v_swizzle(int t) {
+  return D == 64 ? 2 * ((t >> 1) & 3) : 2 * (t & 7);
+}
+
+template <typename T, int D, bool PAGED, int QT, int HW>
+__global__ __launch_bounds__(256) void prefill_lds_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
+    const int32_t* __restrict__ block_tables, int bt_stride, uint16_t* __restrict__ out, int64_t out_stride, int H,
+    int Hkv, int block_size, float scale2) {
+  typedef typename VecOf<T>::x8 frag_t;
+  constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
+  constexpr int QW = 4 / HW;                    // query groups per workgroup
+  constexpr int NC = D == 64 ? 4 : 2;           // chunks per key block
+  constexpr int BK = 32 * NC;                   // keys per block
+  constexpr int K_BYTES = 32 * D * 2;           // one chunk of K (= of V)
+  constexpr int PIECES = 2 * K_BYTES / 1024;    // 1-KiB DMA pieces per chunk: 8 (D = 64) or 16
+  constexpr int LPW = NC * PIECES / 4;          // pieces each wavefront moves per block
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[2][NC][2 * K_BYTES];   // 64 KiB
+
+  const int seq = blockIdx.z;
+  const int G = H / Hkv, groups = (G + HW - 1) / HW;
+  const int kvh = blockIdx.y / groups, hq = blockIdx.y - kvh * groups;
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q0 = cu_q[seq], q_len = cu_q[seq + 1] - q0;
+  const int k0 = cu_k[seq], k_len = cu_k[seq + 1] - k0;
+  const int bx = gridDim.x - 1 - blockIdx.x;    // late query blocks see the most keys: start them first
+  const int wg_q = bx * (QW * 16 * QT);         // first query of the workgroup
+  if (wg_q >= q_len) return;                    // uniform over the workgroup
+  const int head_local = hq * HW + (wid % HW);
+  const int qt = wg_q + (wid / HW) * (16 * QT); // first query of this wavefront
+  const bool active = head_local < G && qt < q_len;
+  const int head = kvh * G + (head_local < G ? head_local : 0);
+
+  int limit[QT], tile_keys[QT], tile_clear[QT];
+  bool live[QT];
+  frag_t qf[QT][KS];
+  AttnState<T, D> st[QT];
+  int my_keys = 0;            // extent of this wavefront's own loop
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    const int t0 = qt + 16 * i, qi = t0 + c;
+    live[i] = active && qi < q_len;
+    limit[i] = live[i] ? (k_len - q_len + qi + 1) : 0;   // bottom-right aligned causal mask
+    int last_q = t0 + 15;
+    if (last_q > q_len - 1) last_q = q_len - 1;
+    const bool exists = active && t0 < q_len;
+    tile_keys[i] = exists ? (k_len - q_len + last_q + 1) : 0;          // keys any column of the tile can see
+    tile_clear[i] = (exists && t0 + 15 < q_len) ? (k_len - q_len + t0 + 1) : 0;   // keys EVERY column sees
+    my_keys = tile_keys[i] > my_keys ? tile_keys[i] : my_keys;
+    const uint16_t* qr = q + (int64_t)(q0 + (live[i] ? qi : wg_q)) * q_stride + (int64_t)head * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(qr + 32 * ks);
+      if (!live[i]) t = u32x4{0, 0, 0, 0};
+      qf[i][ks] = __builtin_bit_cast(frag_t, t);
+    }
+    st[i].m = -INFINITY;
+    st[i].l = 0.f;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) st[i].acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int wg_last = wg_q + QW * 16 * QT - 1;
+  if (wg_last > q_len - 1) wg_last = q_len - 1;
+  const int wg_keys = k_len - q_len + wg_last + 1;     // keys the workgroup's last query sees
+  const int n_blocks = (wg_keys + BK - 1) / BK;
+
+  const int64_t row_stride = PAGED ? (int64_t)Hkv * D : kv_stride;
+  const uint16_t* k_base = k + (int64_t)kvh * D;
+  const uint16_t* v_base = v + (int64_t)kvh * D;
+  const int32_t* bt_row = PAGED ? block_tables + (int64_t)seq * bt_stride : nullptr;
+  const int64_t max_row = (int64_t)k0 + k_len - 1;     // packed keys: never read past the sequence
+
+  // Issue this wavefront's LPW pieces of key block `blk` into ring half `half`.
+  auto issue = [&](int blk, int half) {
+    const int base0 = blk * BK;
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      const int base = base0 + 32 * cc;
+      int64_t rows[2];   // first cache row of the chunk's two 16-token tiles (wave-uniform)
+      if (PAGED) {       // tiles that start at or past k_len have no table entry: they re-read the block's first tile
+        const int64_t r00 = paged_tile_row(bt_row, base0, block_size);
+        rows[0] = base < k_len ? paged_tile_row(bt_row, base, block_size) : r00;
+        rows[1] = base + 16 < k_len ? paged_tile_row(bt_row, base + 16, block_size) : r00;
+      } else {
+        rows[0] = k0 + base;
+        rows[1] = k0 + base + 16;
+      }
+#pragma unroll
+      for (int n = 0; n < PIECES / 4; ++n) {
+        const int piece = wid + 4 * n;            // wave-uniform
+        const uint16_t* src;
+        if (piece < PIECES / 2) {                 // K fragment (tl, ks)
+          const int tl = piece / KS, ks = piece - tl * KS;
+          int64_t row = rows[tl] + c;
+          if (!PAGED && row > max_row) row = max_row;
+          src = k_base + row * row_stride + 32 * ks + 8 * g;
+        } else {
+          const int vp = piece - PIECES / 2;
+          int t, col;   // LDS slot `lane` of this piece = (row t, swizzled piece); fetch the piece that belongs there
+          if constexpr (D == 64) {
+            t = 8 * vp + (lane >> 3);
+            col = 8 * ((lane & 7) ^ v_swizzle<D>(t));
+          } else {
+            t = 4 * vp + (lane >> 4);
+            col = 8 * ((lane & 15) ^ v_swizzle<D>(t));
+          }
+          int64_t row = rows[t >> 4] + (t & 15);
+          if (!PAGED && row > max_row) row = max_row;
+          src = v_base + row * row_stride + col;
+        }
+        __builtin_amdgcn_global_load_lds((global_void_t*)src, (lds_void_t*)&ring[half][cc][piece * 1024], 16, 0, 0);
+      }
+    }
+  };
+  auto fetch_k = [&](const unsigned char* slot, frag_t (&kf)[2][KS]) {
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        kf[tl][ks] = *reinterpret_cast<const frag_t*>(slot + (tl * KS + ks) * 1024 + lane * 16);
+  };
+  // byte offset, inside a chunk's V image, of this lane's transposed-read address for MFMA m and the chunk's first
+  // 16 tokens (the second 16 are 16 rows further): lane 4 q + p of group g points at row 4 g + q, d = 16 m + 4 p
+  int vaddr[NM];
+  {
+    const int qq = (lane & 15) >> 2, pp = lane & 3, t = 4 * g + qq;
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+      vaddr[m] = K_BYTES + t * (2 * D) + (((2 * m + (pp >> 1)) ^ v_swizzle<D>(t)) << 4) + (pp & 1) * 8;
+  }
+  // V^T fragments of one chunk; TAIL zeroes the tokens at or past k_len (stale cache rows may hold NaN patterns)
+  auto fetch_vt = [&](const unsigned char* slot, int base, bool tail, frag_t (&vt)[NM]) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s lds_v4s_t;
+    uint32_t keep[4] = {~0u, ~0u, ~0u, ~0u};
+    if (tail) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int tok = base + ((e < 4) ? (4 * g + e) : (16 + 4 * g + e - 4));
+        if (tok >= k_len) keep[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(slot + vaddr[m]));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(slot + vaddr[m] + 16 * 2 * D));
+      const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+      vt[m] = __builtin_bit_cast(frag_t, u32x4{l2[0] & keep[0], l2[1] & keep[1], h2[0] & keep[2], h2[1] & keep[3]});
+    }
+  };
+
+  issue(0, 0);
+  for (int blk = 0; blk < n_blocks; ++blk) {
+    wait_vmcnt<0>();                         // this wavefront's pieces of block blk have landed
+    __builtin_amdgcn_s_barrier();
+    if (blk + 1 < n_blocks) issue(blk + 1, (blk + 1) & 1);
+    const int base = blk * BK;
+    if (base >= my_keys) continue;           // wave-uniform: early query groups and idle head slots only move data
+    const unsigned char* half = &ring[blk & 1][0][0];
+
+    // ---- S^T = K . Q^T for the whole block, K fragments straight from LDS
+    f32x4 s[QT][NC][2];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      frag_t kf[2][KS];
+      fetch_k(half + cc * 2 * K_BYTES, kf);
+#pragma unroll
+      for (int i = 0; i < QT; ++i)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          s[i][cc][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) s[i][cc][tl] = mfma16(kf[tl][ks], qf[i][ks], s[i][cc][tl]);
+        }
+    }
+    // ---- one softmax step per tile; blocks wholly below the tile's diagonal need no mask
+    frag_t pf[QT][NC];
+    bool all_clear = true;
+#pragma unroll
+    for (int i = 0; i < QT; ++i) all_clear = all_clear && (base + BK <= tile_clear[i]);
+    if (all_clear) {   // straight-line code for all tiles: their serial softmax chains can be interleaved
+#pragma unroll
+      for (int i = 0; i < QT; ++i) block_softmax<T, D, NC, false>(st[i], s[i], base, limit[i], scale2, pf[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < QT; ++i) block_softmax<T, D, NC, true>(st[i], s[i], base, limit[i], scale2, pf[i]);
+    }
+    // ---- O^T += V^T . P^T, V^T fragments by transposed LDS reads, shared by all tiles
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      frag_t vt[NM];
+      fetch_vt(half + cc * 2 * K_BYTES, base + 32 * cc, base + 32 * cc + 32 > k_len, vt);
+#pragma unroll
+      for (int i = 0; i < QT; ++i) chunk_pv<T, D>(st[i], vt, pf[i][cc]);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    float l = st[i].l;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (!live[i]) continue;
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    uint16_t* orow = out + (int64_t)(q0 + qt + 16 * i + c) * out_stride + (int64_t)head * D + 4 * g;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {   // MFMA m produced d = 16 m + 4 g + r in register r
+      u32x2 w;
+      w[0] = pack2<T>(st[i].acc[m][0] * inv, st[i].acc[m][1] * inv);
+      w[1] = pack2<T>(st[i].acc[m][2] * inv, st[i].acc[m][3] * inv);
+      *reinterpret_cast<u32x2*>(orow + 16 * m) = w;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 // Wavefronts per workgroup: as many as fit the register file (D=128 holds two chunks of K/V in ~200 VGPRs).
 static int decode_waves(int D) {
@@ -734,6 +1027,41 @@ extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* 
     else LAUNCH_PRE_Q(TT, DD, PP, 1, false);                                    \
   } while (0)
   const bool paged = block_tables != nullptr;
+  static int use_lds = -1;
+  if (use_lds < 0) {
+    const char* e = getenv("NV_PREFILL_LDS");   // measurement aid: 0 selects the register-fed kernel
+    use_lds = e ? atoi(e) : 1;
+  }
+  if (use_lds) {
+    const int G = H / Hkv;
+    const int hw = G >= 3 ? 4 : G;               // query heads per workgroup; the other wavefronts take query groups
+    const int groups = (G + hw - 1) / hw;
+    NV_CHECK_ARG((int64_t)Hkv * groups <= 65535, "nv_attn_prefill: too many heads for one launch");
+#define LAUNCH_LDS(TT, DD, PP, QQ, HH)                                                                              \
+  do {                                                                                                              \
+    dim3 lgrid((max_seqlen_q + (4 / HH) * 16 * QQ - 1) / ((4 / HH) * 16 * QQ), Hkv * groups, num_seqs);            \
+    prefill_lds_kernel<TT, DD, PP, QQ, HH><<<lgrid, block, 0, s>>>(                                                 \
+        (const uint16_t*)q, q_row_stride, (const uint16_t*)k, (const uint16_t*)v, kv_row_stride, cu_seqlens_q,      \
+        cu_seqlens_k, block_tables, bt_stride, (uint16_t*)out, out_row_stride, H, Hkv, block_size, scale2);         \
+  } while (0)
+#define LAUNCH_LDS_H(TT, DD, PP, QQ)                                            \
+  do {                                                                          \
+    if (hw == 4) LAUNCH_LDS(TT, DD, PP, QQ, 4);                                 \
+    else if (hw == 2) LAUNCH_LDS(TT, DD, PP, QQ, 2);                            \
+    else LAUNCH_LDS(TT, DD, PP, QQ, 1);                                         \
+  } while (0)
+#define LAUNCH_LDS_T(TT)                                                                                  \
+  do {                                                                                                    \
+    if (D == 128) { if (paged) LAUNCH_LDS_H(TT, 128, true, NV_PREFILL_QT128); else LAUNCH_LDS_H(TT, 128, false, NV_PREFILL_QT128); } \
+    else          { if (paged) LAUNCH_LDS_H(TT, 64, true, NV_PREFILL_QT64); else LAUNCH_LDS_H(TT, 64, false, NV_PREFILL_QT64); }     \
+  } while (0)
+    if (dtype == NV_BF16) LAUNCH_LDS_T(bf16_t); else LAUNCH_LDS_T(f16_t);
+#undef LAUNCH_LDS_T
+#undef LAUNCH_LDS_H
+#undef LAUNCH_LDS
+    NV_CHECK_LAUNCH();
+    return NV_OK;
+  }
   if (dtype == NV_BF16) {
     if (D == 128) { if (paged) LAUNCH_PRE(bf16_t, 128, true); else LAUNCH_PRE(bf16_t, 128, false); }
     else          { if (paged) LAUNCH_PRE(bf16_t, 64, true); else LAUNCH_PRE(bf16_t, 64, false); }
