@@ -27,16 +27,19 @@
 // sum) go to the workspace for a small combine kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
-// Query tiles (of 16) per wavefront in the LDS-fed prefill kernel.  One tile keeps two workgroups per CU (~185
-// registers); two tiles halve the LDS reads per flop but run one workgroup per CU and measured 20-35 % slower.
+// Query tiles (of 16) per wavefront in the LDS-fed prefill kernel: two halve the LDS reads per flop and still fit
+// the 256 registers that two workgroups per CU leave each wavefront (measured against one tile: 8 x 1024 tokens
+// 59 vs 65 us at D = 64, 165 vs 181 us at D = 128; four tiles need one workgroup per CU and lose).
 #ifndef NV_PREFILL_QT64
-#define NV_PREFILL_QT64 1
+#define NV_PREFILL_QT64 2
 #endif
 #ifndef NV_PREFILL_QT128
-#define NV_PREFILL_QT128 1
+#define NV_PREFILL_QT128 2
 #endif
 
 template <int D> struct AttnGeom {
@@ -694,7 +697,7 @@ template <int D> __device__ __forceinline__ int v_swizzle(int t) {
 }
 
 template <typename T, int D, bool PAGED, int QT, int HW>
-__global__ __launch_bounds__(256) void prefill_lds_kernel(
+__global__ __launch_bounds__(256, 2) void prefill_lds_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int bt_stride, uint16_t* __restrict__ out, int64_t out_stride, int H,
@@ -763,6 +766,23 @@ __global__ __launch_bounds__(256) void prefill_lds_kernel(
   const int32_t* bt_row = PAGED ? block_tables + (int64_t)seq * bt_stride : nullptr;
   const int64_t max_row = (int64_t)k0 + k_len - 1;     // packed keys: never read past the sequence
 
+  // The wavefront's pieces of a chunk are wid, wid + 4, ...: which operand, which 16-token tile and which lane offset
+  // inside that tile a piece takes never changes, so they are worked out once (the offset fits 32 bits: a tile spans
+  // 16 cache rows) and the loop adds a wave-uniform tile address, which the DMA takes as its scalar base.
+  uint32_t piece_off[PIECES / 4];
+#pragma unroll
+  for (int n = 0; n < PIECES / 4; ++n) {
+    const int piece = wid + 4 * n;
+    if (piece < PIECES / 2) {
+      const int ks = piece % KS;
+      piece_off[n] = (uint32_t)(c * (int)row_stride + 32 * ks + 8 * g) * 2u;
+    } else {
+      const int vp = piece - PIECES / 2;
+      const int t = D == 64 ? 8 * vp + (lane >> 3) : 4 * vp + (lane >> 4);
+      const int col = D == 64 ? 8 * ((lane & 7) ^ v_swizzle<D>(t)) : 8 * ((lane & 15) ^ v_swizzle<D>(t));
+      piece_off[n] = (uint32_t)((t & 15) * (int)row_stride + col) * 2u;
+    }
+  }
   // Issue this wavefront's LPW pieces of key block `blk` into ring half `half`.
   auto issue = [&](int blk, int half) {
     const int base0 = blk * BK;
@@ -777,6 +797,19 @@ __global__ __launch_bounds__(256) void prefill_lds_kernel(
       } else {
         rows[0] = k0 + base;
         rows[1] = k0 + base + 16;
+      }
+      if (PAGED || base + 32 <= k_len) {   // every row of the chunk exists: scalar tile base + constant lane offset
+#pragma unroll
+        for (int n = 0; n < PIECES / 4; ++n) {
+          const int piece = wid + 4 * n;
+          const bool is_k = piece < PIECES / 2;
+          const int vp = piece - PIECES / 2;
+          const int tile = is_k ? piece / KS : (D == 64 ? vp >> 1 : vp >> 2);
+          const char* tb = reinterpret_cast<const char*>((is_k ? k_base : v_base) + rows[tile] * row_stride);
+          __builtin_amdgcn_global_load_lds((global_void_t*)(tb + piece_off[n]),
+                                           (lds_void_t*)&ring[half][cc][piece * 1024], 16, 0, 0);
+        }
+        continue;
       }
 #pragma unroll
       for (int n = 0; n < PIECES / 4; ++n) {
@@ -822,11 +855,11 @@ __global__ __launch_bounds__(256) void prefill_lds_kernel(
       vaddr[m] = K_BYTES + t * (2 * D) + (((2 * m + (pp >> 1)) ^ v_swizzle<D>(t)) << 4) + (pp & 1) * 8;
   }
   // V^T fragments of one chunk; TAIL zeroes the tokens at or past k_len (stale cache rows may hold NaN patterns)
-  auto fetch_vt = [&](const unsigned char* slot, int base, bool tail, frag_t (&vt)[NM]) {
+  auto fetch_vt = [&](const unsigned char* slot, int base, auto tail, frag_t (&vt)[NM]) {
     typedef short v4s __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4s lds_v4s_t;
     uint32_t keep[4] = {~0u, ~0u, ~0u, ~0u};
-    if (tail) {
+    if constexpr (decltype(tail)::value) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int tok = base + ((e < 4) ? (4 * g + e) : (16 + 4 * g + e - 4));
@@ -838,7 +871,10 @@ __global__ __launch_bounds__(256) void prefill_lds_kernel(
       const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(slot + vaddr[m]));
       const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(slot + vaddr[m] + 16 * 2 * D));
       const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-      vt[m] = __builtin_bit_cast(frag_t, u32x4{l2[0] & keep[0], l2[1] & keep[1], h2[0] & keep[2], h2[1] & keep[3]});
+      if constexpr (decltype(tail)::value)
+        vt[m] = __builtin_bit_cast(frag_t, u32x4{l2[0] & keep[0], l2[1] & keep[1], h2[0] & keep[2], h2[1] & keep[3]});
+      else
+        vt[m] = __builtin_bit_cast(frag_t, u32x4{l2[0], l2[1], h2[0], h2[1]});
     }
   };
 
@@ -882,7 +918,8 @@ __global__ __launch_bounds__(256) void prefill_lds_kernel(
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) {
       frag_t vt[NM];
-      fetch_vt(half + cc * 2 * K_BYTES, base + 32 * cc, base + 32 * cc + 32 > k_len, vt);
+      if (base + 32 * cc + 32 <= k_len) fetch_vt(half + cc * 2 * K_BYTES, base + 32 * cc, std::false_type{}, vt);
+      else fetch_vt(half + cc * 2 * K_BYTES, base + 32 * cc, std::true_type{}, vt);
 #pragma unroll
       for (int i = 0; i < QT; ++i) chunk_pv<T, D>(st[i], vt, pf[i][cc]);
     }
