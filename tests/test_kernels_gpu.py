@@ -308,6 +308,43 @@ def test_gemm_dense_and_dequant(name, M, N, K, fmt, split_k):
     ulp_close(got, want.to(dt), name, ulps=1.0)
 
 
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("M,N,K", [(512, 128, 128), (777, 256, 384), (1300, 1152, 896)])
+@pytest.mark.parametrize("fmt", ["tiled", "w8a16", "w4a16"])
+def test_gemm_many_rows(name, M, N, K, fmt):
+    """Prefill-sized M (many 128-row tiles, a ragged last one): same contract as at decode sizes."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    dt = DT[name]
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt)
+    if fmt == "tiled":
+        lw, w_ref = LinearWeight.dense_tiled(dev(w)), w
+    elif fmt == "w4a16":
+        lw, w_ref = LinearWeight.make(dev(w), fmt), Q.dequantize_w4(*Q.quantize_w4(w))
+    else:
+        lw, w_ref = LinearWeight.make(dev(w), fmt), Q.dequantize_w8(*Q.quantize_w8(w))
+    want = torch.nn.functional.linear(x.double(), w_ref.double(), bias.double())
+    got = kernels.gemm(dev(x), lw, dev(bias))
+    ulp_close(got, want.to(dt), name, ulps=1.0)
+
+
+@pytest.mark.parametrize("M", [640, 2100])
+def test_gemm_many_rows_silu_mul(M):
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    g = torch.Generator().manual_seed(23)
+    K, inter = 256, 1536
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inter, K, generator=g) * 0.05).to(torch.bfloat16)
+    want = L.silu_and_mul(L.linear(x, Q.dequantize_w4(*Q.quantize_w4(w))))
+    got = kernels.gemm(dev(x), LinearWeight.make(interleave_gate_up(dev(w)), "w4a16"), silu_mul=True)
+    assert got.shape == (M, inter)
+    ulp_close(got, want, "bf16", ulps=2.0)
+
+
 @pytest.mark.parametrize("fmt", ["dense", "w4a16"])
 @pytest.mark.parametrize("M", [5, 128])
 def test_gemm_silu_mul_epilogue(fmt, M):
