@@ -120,7 +120,7 @@ __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k
 // One loaded chunk against one 16-column query tile, in three steps so that several query tiles can share the
 // chunk's registers: scores + online softmax (per tile), V^T operands (once per chunk), P.V (per tile).
 //  limit: number of visible keys for this lane's column; base: first token of the chunk.
-template <typename T, int D>
+template <typename T, int D, bool MASK = true>
 __device__ __forceinline__ typename VecOf<T>::x8 chunk_scores(AttnState<T, D>& st, const ChunkRegs<T, D>& r,
                                                               const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS],
                                                               int base, int limit, float scale2) {
@@ -137,30 +137,32 @@ __device__ __forceinline__ typename VecOf<T>::x8 chunk_scores(AttnState<T, D>& s
     for (int ks = 0; ks < KS; ++ks) s[tl] = mfma16(r.kf[tl][ks], qf[ks], s[tl]);
   }
 
-  // ---- online softmax, column-local
+  // ---- online softmax, column-local.  MASK = false: the caller knows every key of the chunk is visible.
+  // scale2 > 0, so the maximum of the scaled scores is the scaled maximum of the raw ones and the scale can ride
+  // in the exponent's fma; v_exp_f32 directly (its arguments are <= 0, flushed denormal results are zeros anyway).
   float cmax = -INFINITY;
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int tok = base + 16 * tl + 4 * g + rr;
-      float x = s[tl][rr] * scale2;
-      x = (tok < limit) ? x : -INFINITY;
-      s[tl][rr] = x;
-      cmax = fmaxf(cmax, x);
+      if (MASK) {
+        const int tok = base + 16 * tl + 4 * g + rr;
+        s[tl][rr] = (tok < limit) ? s[tl][rr] : -INFINITY;
+      }
+      cmax = fmaxf(cmax, s[tl][rr]);
     }
   cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
   cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-  const float m_new = fmaxf(st.m, cmax);
+  const float m_new = fmaxf(st.m, cmax * scale2);
   const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-  const float alpha = (st.m == -INFINITY) ? 0.f : exp2f(st.m - m_use);
+  const float alpha = (st.m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st.m - m_use);
   float psum = 0.f;
   frag_t pf;
 #pragma unroll
   for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const float p = exp2f(s[tl][rr] - m_use);
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[tl][rr], scale2, -m_use));
       psum += p;
       pf[tl * 4 + rr] = (T)p;
     }
@@ -209,14 +211,14 @@ __device__ __forceinline__ void chunk_pv(AttnState<T, D>& st, const typename Vec
 }
 
 // The two MFMA products and the online softmax for one loaded chunk and one query tile.
-template <typename T, int D, bool TAIL>
+template <typename T, int D, bool TAIL, bool MASK = true>
 __device__ __forceinline__ void chunk_compute(AttnState<T, D>& st, ChunkRegs<T, D>& r,
                                               const typename VecOf<T>::x8 (&qf)[AttnGeom<D>::KS], int base, int limit,
                                               int n_keys, float scale2) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, g = lane >> 4;
-  const frag_t pf = chunk_scores<T, D>(st, r, qf, base, limit, scale2);
+  const frag_t pf = chunk_scores<T, D, MASK>(st, r, qf, base, limit, scale2);
   // same arithmetic as chunk_v_operands + chunk_pv, but each V^T fragment is built right before its MFMA: with a
   // single query tile that keeps eight fewer fragments alive
   if (TAIL) {
@@ -327,13 +329,13 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
   int ch = split * NW + wid;
   auto compute = [&](ChunkRegs<T, D>& r, int chunk) {
     const int base = chunk << 5;
-    if (base + 32 <= n_keys) chunk_compute<T, D, false>(st, r, qf, base, n_keys, n_keys, scale2);
+    if (base + 32 <= n_keys) chunk_compute<T, D, false, false>(st, r, qf, base, n_keys, n_keys, scale2);
     else chunk_compute<T, D, true>(st, r, qf, base, n_keys, n_keys, scale2);
   };
   // a chunk that has a successor in this wavefront's sequence is not the sequence's last chunk, so all of its 32
   // keys exist: the steady-state loop body carries no masking code
   auto compute_full = [&](ChunkRegs<T, D>& r, int chunk) {
-    chunk_compute<T, D, false>(st, r, qf, chunk << 5, n_keys, n_keys, scale2);
+    chunk_compute<T, D, false, false>(st, r, qf, chunk << 5, n_keys, n_keys, scale2);
   };
   if constexpr (D > 64) {
     // 128-wide heads: with two alternating register sets the unrolled loop needs more than 256 registers (it spills
