@@ -1,0 +1,30 @@
+"""bench.py with two ranks on one GPU: the multi-rank launch path (torch.distributed.run, barrier, max over ranks,
+rank-0 JSON line) in both modes.  RCCL wants one device per rank, so the ranks talk over gloo (NV_BENCH_BACKEND)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode", ["dp", "tp"])
+def test_bench_two_ranks(mode):
+    env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533" if mode == "dp" else "29534",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--workload", "qwen2-0.5b-fp16-b1-s128", "--parallelism", mode]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]          # exactly one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    assert d["scaling"] == ("weak" if mode == "dp" else "strong")
+    assert d["config"]["parallelism"] == f"{mode}2"
+    assert "cpu_baseline" not in d                      # rank 0 times the CPU baseline at N = 1 only
