@@ -132,14 +132,15 @@ def _oracle_generate(cfg, weights, prompts, max_tokens, num_blocks):
     return [s.completion_token_ids for s in seqs], min(margins)
 
 
+@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
 @pytest.mark.parametrize("eager", [True, False])
-def test_engine_greedy_tokens_match_oracle(golden, eager):
+def test_engine_greedy_tokens_match_oracle(golden, eager, style):
     """LLM.generate (scheduler + block manager + runner, hipGraph decode when eager=False) vs the oracle loop."""
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     get_rope.cache_clear()
-    _, _, weights = _golden_weights(golden, "qwen2")
-    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    _, _, weights = _golden_weights(golden, style)
+    cfg = OM.tiny_config(style, torch.bfloat16)
     rng = np.random.RandomState(3)
     prompts = [rng.randint(0, 256, size=n).tolist() for n in (5, 19, 33, 16)]
     want, margin = _oracle_generate(cfg, weights, prompts, max_tokens=12, num_blocks=16)
