@@ -9,10 +9,13 @@ resident in HBM.  Rank 0 prints ONE JSON line; `value` is whole-job decode
 tokens/s, `roofline` prices the paged-attention kernel against HBM peak and
 `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
 
-For N > 1 launch under torch.distributed.run (one rank per GPU).  `dp` runs one
-independent replica per GPU (no data-path collective; the 0.5B model's 14/2
-heads do not split 8 ways under the reference's sharding rules); `tp` shards
-the linears column/row-wise with RCCL all-reduce, as the reference does.
+For N > 1 launch under torch.distributed.run (one rank per GPU).  The default
+there is `--parallelism tp`: the reference's own split (column/row-sharded
+linears, RCCL all-reduce over xGMI captured inside the decode graph, logits
+gather), the SAME batch spread over N GPUs ("scaling": "strong").  After the
+timed tensor-parallel run the same job also times N independent replicas of the
+single-GPU step (no data-path collective) and reports that as the extra key
+`replicas_tok_s`; `--parallelism dp` makes the replicas the headline instead.
 """
 
 import argparse
@@ -179,7 +182,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
-    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"])
+    ap.add_argument("--parallelism", default=None, choices=["dp", "tp"],
+                    help="N > 1: tp (default) = one model sharded over the ranks; dp = one replica per rank")
+    ap.add_argument("--no-replicas", action="store_true", help="tp: skip the extra replicas_tok_s leg")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
@@ -209,6 +214,8 @@ def main():
 
     model_name, quantization, dtype_name, batch, context = WORKLOADS[args.workload]
     hf = qwen2_config(model_name, dtype=DTYPES[dtype_name])
+    if args.parallelism is None:
+        args.parallelism = "tp" if world > 1 else "dp"
     tp = world if (args.parallelism == "tp" and world > 1) else 1
     if tp > 1:
         assert hf.num_key_value_heads % tp == 0 or tp % hf.num_key_value_heads == 0, (
@@ -217,32 +224,40 @@ def main():
     block_size = 256
     total_steps = args.warmup + args.steps + 2
     blocks_per_seq = (context + total_steps) // block_size + 1
-    config = Config("synthetic", hf_config=hf, quantization=quantization, tensor_parallel_size=tp,
-                    kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
-                    max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
-                    max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
-                    enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp == 1 else 0)
-    runner = ModelRunner(config, rank if tp > 1 else 0, None)
-    runner.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
-    seqs, next_block = make_sequences(batch, context, block_size)
-    driver = StepDriver(runner, seqs, next_block, tp)
 
-    for _ in range(args.warmup):
-        driver.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        driver.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def build(tp_size):
+        config = Config("synthetic", hf_config=hf, quantization=quantization, tensor_parallel_size=tp_size,
+                        kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
+                        max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
+                        max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
+                        enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0)
+        r = ModelRunner(config, rank if tp_size > 1 else 0, None)
+        r.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
+        seqs_, next_block = make_sequences(batch, context, block_size)
+        return r, seqs_, StepDriver(r, seqs_, next_block, tp_size)
+
+    def timed(driver):
+        """W untimed steps, then K steps between barrier + synchronize on both sides; the MAX over ranks."""
+        for _ in range(args.warmup):
+            driver.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            driver.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+    runner, seqs, driver = build(tp)
+    elapsed = timed(driver)
 
     replicas = world // tp
     tokens = batch * args.steps * replicas
@@ -273,6 +288,9 @@ def main():
                        "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
                        "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": not args.eager,
                        "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
+            "graph_captured": not runner.enforce_eager,
             "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": bytes_step,
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ decode_combine_kernel)",
@@ -282,8 +300,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and (model_name != "qwen2-7b" or args.cpu_baseline_7b):
             line["cpu_baseline"] = cpu_baseline(model_name, quantization, DTYPES[dtype_name], batch, context)
-        print(json.dumps(line), flush=True)
     runner.exit()
+    if tp > 1 and not args.no_replicas:
+        # the same job as N independent replicas of the single-GPU step: what the hardware does with this workload
+        # when no collective sits on the critical path (every rank takes part: the timing has barriers)
+        del runner, driver
+        torch.cuda.empty_cache()
+        from byox_vllm_amd.layers.rotary_embedding import get_rope
+        get_rope.cache_clear()
+        runner, seqs, driver = build(1)
+        rep_elapsed = timed(driver)
+        runner.exit()
+        if rank == 0:
+            line["replicas_tok_s"] = round(batch * args.steps * world / rep_elapsed, 1)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

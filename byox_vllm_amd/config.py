@@ -8,8 +8,6 @@ Differences from the reference, all supersets:
   because of flash-attn; the HIP kernels take the block size at run time).
 * ``state_dict`` supplies an in-memory checkpoint (packed parameter names) instead
   of safetensors files; with neither, synthetic weights are drawn from ``seed``.
-* ``decode_microbatches`` runs the captured decode step as that many independent
-  micro-batches on parallel HIP streams (small models leave most CUs idle per kernel).
 * ``quantization`` selects the weight format of the layer linears:
   ``None`` (dense), ``"w8a16"`` or ``"w4a16"``.
 """
@@ -58,7 +56,7 @@ class Config:
     num_kvcache_blocks: int = -1
     quantization: str | None = None
     seed: int = 0
-    decode_microbatches: int = 0    # decode graph: split the batch over this many parallel HIP streams (0 = auto)
+    graph_head: bool = True         # single rank: LM head + sampler inside the decode graph (False: forward only)
     graph_batch_sizes: Any = None   # optional list: capture decode graphs only for these padded batch sizes
     state_dict: Any = None   # optional in-memory checkpoint keyed by the packed parameter names
 

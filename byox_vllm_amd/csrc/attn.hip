@@ -946,15 +946,16 @@ __global__ __launch_bounds__(256, 2) void prefill_lds_kernel(
 }
 
 // ------------------------------------------------------------------ C ABI
-// Wavefronts per workgroup: as many as fit the register file (D=128 holds two chunks of K/V in ~200 VGPRs).
+// Wavefronts per workgroup: 8 (two per SIMD cover each other's waits; D=128 holds two chunks of K/V in ~200 VGPRs).
+// NV_ATTN_WAVES (4, 8, or 16 at D=64) selects another instantiation; read on every call so one process can
+// compare them.
 static int decode_waves(int D) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("NV_ATTN_WAVES");   // tuning aid
-    forced = e ? atoi(e) : 0;
+  if (const char* e = getenv("NV_ATTN_WAVES")) {
+    const int forced = atoi(e);
+    if (forced == 4 || forced == 8) return forced;
+    if (forced == 16) return D == 128 ? 8 : 16;
   }
-  if (forced == 4 || forced == 8 || forced == 16) return (D == 128 && forced == 16) ? 8 : forced;
-  return D == 128 ? 8 : 8;
+  return 8;
 }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
@@ -974,11 +975,12 @@ extern "C" size_t nv_paged_attn_decode_workspace_bytes(int B, int H, int D, int 
   return (size_t)B * H * num_splits * (D + 2) * sizeof(float);
 }
 
-extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
-                                    const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
-                                    void* out, int64_t out_row_stride, void* workspace, size_t workspace_bytes, int B,
-                                    int H, int Hkv, int D, int block_size, float scale, int num_splits, int dtype,
-                                    nv_stream_t stream) {
+// Argument checks and launches shared by nv_paged_attn_decode (caller's workspace) and nv_paged_attn_decode_static
+// (the library's own per-device array).
+static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                           const int32_t* block_tables, int bt_stride, const int32_t* context_lens, void* out,
+                           int64_t out_row_stride, void* workspace, size_t workspace_bytes, int B, int H, int Hkv,
+                           int D, int block_size, float scale, int num_splits, int dtype, nv_stream_t stream) {
   NV_CHECK_ARG(q && k_cache && v_cache && block_tables && context_lens && out, "nv_paged_attn_decode: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_paged_attn_decode: bad dtype %d", dtype);
   NV_CHECK_ARG(D == 64 || D == 128, "nv_paged_attn_decode: head_dim %d not in {64, 128}", D);
@@ -1028,6 +1030,15 @@ extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const v
     NV_CHECK_LAUNCH();
   }
   return NV_OK;
+}
+
+extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                                    const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
+                                    void* out, int64_t out_row_stride, void* workspace, size_t workspace_bytes, int B,
+                                    int H, int Hkv, int D, int block_size, float scale, int num_splits, int dtype,
+                                    nv_stream_t stream) {
+  return paged_decode_go(q, q_row_stride, k_cache, v_cache, block_tables, bt_stride, context_lens, out, out_row_stride,
+                         workspace, workspace_bytes, B, H, Hkv, D, block_size, scale, num_splits, dtype, stream);
 }
 
 extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* k, const void* v,

@@ -127,6 +127,7 @@ class BlockManager:
         if rem == 1:
             # the token just appended opens a new block
             assert last.hash != -1
+            Sequence.table_epoch += 1
             table.append(self._take(self.blocks[self.free_block_ids[0]]).block_id)
         elif rem == 0:
             # last block just became full: give it its chained hash

@@ -87,17 +87,20 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ weights
     def _load_weights(self):
+        """Checkpoint -> parameters (nanovllm model_runner.py:33).  Synthetic weights are drawn only when the caller
+        asked for them (model == "synthetic"); a directory without safetensors files is an error, as in the reference."""
         import glob
-        import os
         path = self.config.model
         if self.config.state_dict is not None:
             from byox_vllm_amd.utils.loader import load_state_dict_packed
             load_state_dict_packed(self.model, self.config.state_dict, self.config.hf_config)
-        elif isinstance(path, str) and os.path.isdir(path) and glob.glob(os.path.join(path, "*.safetensors")):
-            load_model(self.model, path)
-        else:
-            logger.info("no safetensors under %r: drawing synthetic weights (seed %d)", path, self.config.seed)
+        elif path == "synthetic":
+            logger.info("drawing synthetic weights (seed %d)", self.config.seed)
             init_random_weights(self.model, self.config.seed)
+        else:
+            if not (isinstance(path, str) and os.path.isdir(path) and glob.glob(os.path.join(path, "*.safetensors"))):
+                raise FileNotFoundError(f"no *.safetensors under {path!r} (pass model='synthetic' for random weights)")
+            load_model(self.model, path)
 
     # ------------------------------------------------------------------ RPC (tensor parallel)
     def call(self, method_name, *args):
@@ -171,9 +174,6 @@ class ModelRunner:
         n, cols = self._pack_decode(seqs, host[2:])
         host[0], host[1] = bs, cols          # header read on the device by the graph's own staging node
         padded = g["padded_bs"] = next(x for x in self.graph_bs if x >= bs)
-        if padded not in self.graph_stages_itself:
-            self._dev_stage[:n + 2].copy_(self._host_stage[:n + 2], non_blocking=True)
-            kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
         self._replay(padded)
         torch.cuda.current_stream().synchronize()
         return self._host_tokens_np[:bs].tolist()
@@ -182,8 +182,10 @@ class ModelRunner:
         """Fill ``host`` (int32) with one decode step's integers, laid out as nv_stage_decode_packed reads them:
         [last tokens | positions | slots | context lens | temperatures (f32 bits) | block tables bs x cols, -1 padded].
         Same values as _prepare_decode / _prepare_block_tables / _prepare_sample (nanovllm model_runner.py:152-158,
-        206-235).  Returns (words used, cols).  The padded tables are rebuilt only when a table changed: every
-        change of a table alters the total block count, replaces the list object or bumps Sequence.table_epoch."""
+        206-235).  Returns (words used, cols).  The padded tables are rebuilt only when a table changed.  Invariant
+        the cache rests on: for an unchanged list of Sequence objects, every change of a block table bumps
+        Sequence.table_epoch (BlockManager.allocate / deallocate / may_append do) or alters the total block count
+        (a driver that appends block ids by hand)."""
         bs, block = len(seqs), self.block_size
         tables_in = [seq.block_table for seq in seqs]
         lens = list(map(len, tables_in))
@@ -204,7 +206,7 @@ class ModelRunner:
         host[4 * bs:5 * bs].view(np.float32)[:] = cached["temps"]
         tables = host[5 * bs:n].reshape(bs, cols)
         key = (total, cols, Sequence.table_epoch)
-        if cached["key"] == key and cached["tables_in"] == tables_in:
+        if cached["key"] == key:
             tables[:] = cached["tables"]
         else:
             if total == bs * cols:
@@ -213,7 +215,7 @@ class ModelRunner:
                 tables.fill(-1)
                 for i, t in enumerate(tables_in):
                     tables[i, : len(t)] = t
-            cached["key"], cached["tables_in"], cached["tables"] = key, tables_in, tables.copy()
+            cached["key"], cached["tables"] = key, tables.copy()
             cached["last_block_row"] = np.array([t[-1] for t in tables_in], dtype=np.int32) * block
         np.add(cached["last_block_row"], head[1] % block, out=head[2])
         return n, cols
@@ -317,31 +319,7 @@ class ModelRunner:
         return self.model.compute_logits(g["outputs"][:bs])
 
     def _replay(self, padded_bs: int) -> None:
-        """Replay the step's graph(s): micro-batch 0 on the current stream, the others on side streams, then join."""
-        graphs = self.graphs[padded_bs]
-        main = torch.cuda.current_stream()
-        for k in range(1, len(graphs)):
-            side = self._side_streams[k - 1]
-            side.wait_stream(main)               # staged inputs must be visible
-            with torch.cuda.stream(side):
-                graphs[k].replay()
-        graphs[0].replay()
-        for k in range(1, len(graphs)):
-            main.wait_stream(self._side_streams[k - 1])
-
-    def _microbatch_bounds(self, bs: int) -> list[tuple[int, int]]:
-        """Row ranges of the decode micro-batches (Config.decode_microbatches; default one).
-
-        Measured on MI355X, Qwen2-0.5B int4 batch 128: two half-batch graphs on two streams run no faster than
-        one full-batch graph (2.07 vs 1.96 ms/step) because every kernel here already places one workgroup on
-        each CU, so a second queue finds no free CU; the option stays for models whose kernels under-fill the chip."""
-        n = self.config.decode_microbatches
-        if n <= 0:
-            n = 1
-        n = max(1, min(n, 4, bs // 16 if bs >= 16 else 1))
-        per = -(-bs // n)
-        per = -(-per // 16) * 16 if bs >= 16 else per
-        return [(lo, min(lo + per, bs)) for lo in range(0, bs, per)]
+        self.graphs[padded_bs].replay()
 
     def _set_decode_splits(self, bs: int) -> None:
         hkv = self.model.model.layers[0].self_attn.num_kv_heads
@@ -381,7 +359,8 @@ class ModelRunner:
 
     @torch.inference_mode()
     def _capture_graphs(self):
-        """Capture one hipGraph of the decode forward per padded batch size, largest first, sharing one pool."""
+        """Capture one hipGraph of the decode step per padded batch size, largest first, sharing one pool
+        (nanovllm model_runner.py:256-297)."""
         config, hf = self.config, self.config.hf_config
         max_bs = min(config.max_num_seqs, MAX_GRAPH_BS)
         max_blocks = (config.max_model_len + self.block_size - 1) // self.block_size
@@ -404,58 +383,48 @@ class ModelRunner:
         self._dev_stage = torch.zeros(stage_words, dtype=torch.int32, device=dev)
         self._host_tokens = torch.zeros(max_bs, dtype=torch.int64, device="cpu").pin_memory()
         self._host_tokens_np = self._host_tokens.numpy()
-        self.graph_has_head = self.world_size == 1
+        # Single rank: the graph also stages its inputs and ends in LM head + sampler.  With tensor parallelism (or
+        # Config.graph_head = False) it holds the forward only; logits gather and sampling follow outside, as in the
+        # reference (model_runner.py:253-254).
+        self.graph_has_head = self.world_size == 1 and self.config.graph_head
         self.graph_bs = sorted(config.graph_batch_sizes) if config.graph_batch_sizes else graph_batch_sizes(max_bs)
         max_bs = self.graph_bs[-1]
         self.max_graph_bs = max_bs
         self.graphs, self.graph_pool = {}, None
-        self._side_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
-        # padded batch sizes whose graph begins with its own input staging (host buffer -> device -> static inputs)
-        self.graph_stages_itself = set()
-
-        def forward_rows(lo, hi, k, stage_words=0):
-            """Decode forward (+ LM head + sampler on a single rank) for rows [lo, hi) of the static buffers."""
+        def forward_rows(bs, stage_words=0):
+            """Decode forward (+ LM head + sampler on a single rank) for rows [0, bs) of the static buffers."""
             if stage_words:
                 self._dev_stage[:stage_words].copy_(self._host_stage[:stage_words], non_blocking=True)
                 kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
-            self._set_decode_splits(hi - lo)
-            set_context(False, slot_mapping=g["slot_mapping"][lo:hi], context_lens=g["context_lens"][lo:hi],
-                        block_tables=g["block_tables"][lo:hi])
-            hidden = self.model(g["input_ids"][lo:hi], g["positions"][lo:hi])
+            self._set_decode_splits(bs)
+            set_context(False, slot_mapping=g["slot_mapping"][:bs], context_lens=g["context_lens"][:bs],
+                        block_tables=g["block_tables"][:bs])
+            hidden = self.model(g["input_ids"][:bs], g["positions"][:bs])
             if not self.graph_has_head:
-                g["outputs"][lo:hi] = hidden      # the caller computes logits outside the graph (TP gather)
+                g["outputs"][:bs] = hidden        # the caller computes logits outside the graph (TP gather)
             else:                                 # head and sampler inside the graph: no copy of the hidden states
                 logits = self.model.compute_logits(hidden)
-                kernels.sample(logits, g["temperatures"][lo:hi], seed=self.config.seed + 7919 * k,
-                               seed_offset=g["step"], out=g["tokens"][lo:hi])
+                kernels.sample(logits, g["temperatures"][:bs], seed=self.config.seed, seed_offset=g["step"],
+                               out=g["tokens"][:bs])
                 # the graph ends by delivering the tokens to pinned host memory: the host then only waits for the stream
-                self._host_tokens[lo:hi].copy_(g["tokens"][lo:hi], non_blocking=True)
+                self._host_tokens[:bs].copy_(g["tokens"][:bs], non_blocking=True)
 
-        # One graph per micro-batch.  A hipGraph replays its nodes on a single hardware queue even when it was
-        # captured from several streams, so parallelism between micro-batches comes from replaying their
-        # graphs on different streams (_replay).
         for bs in reversed(self.graph_bs):
-            parts = self._microbatch_bounds(bs)
-            graphs = []
-            # a single-rank, single-graph step carries its staging inside the graph: the host then only packs the
-            # pinned buffer and launches one graph
-            words = 2 + bs * (5 + max_blocks) if (self.graph_has_head and len(parts) == 1) else 0
+            # a single-rank step carries its staging inside the graph: the host then only packs the pinned buffer and
+            # launches one graph
+            words = 2 + bs * (5 + max_blocks) if self.graph_has_head else 0
             g["padded_bs"] = bs
             self._host_stage_np[:2] = 0          # warm-up and capture run on an empty step (all rows padding)
-            for k, (lo, hi) in enumerate(parts):
-                forward_rows(lo, hi, k, words)   # warm-up: sizes every workspace before anything is captured
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, self.graph_pool):
-                    forward_rows(lo, hi, k, words)
-                if self.graph_pool is None:
-                    self.graph_pool = graph.pool()
-                graphs.append(graph)
-                torch.cuda.synchronize()
-            self.graphs[bs] = graphs
-            if words:
-                self.graph_stages_itself.add(bs)
+            forward_rows(bs, words)              # warm-up: sizes every workspace before anything is captured
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, self.graph_pool):
+                forward_rows(bs, words)
+            if self.graph_pool is None:
+                self.graph_pool = graph.pool()
+            torch.cuda.synchronize()
+            self.graphs[bs] = graph
             reset_context()
         self.graph_vars = g
 

@@ -87,3 +87,35 @@ def attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, scale, block_tables=None):
             vi = _gather_paged(v, block_tables[i], k1 - k0)
         out[q0:q1] = _attend(q[q0:q1], ki, vi, scale, (k1 - k0) - (q1 - q0))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# How far a correct 16-bit kernel may sit from the functions above.  flash-attn (and the HIP kernels) round the
+# softmax numerators P to the model dtype before P.V while the restatement keeps them in fp32, and both round the
+# output once.  With u = half a unit in the last place of the model dtype (2^-9 bf16, 2^-12 fp16) that gives
+#     |dO| <= u * sum_j p_j |v_j|   (P rounding)  +  2 u |O|   (two output roundings)
+# The tests allow three times the first term and one full ulp (4 u |O|) for the second.
+UNIT_ROUNDOFF = {torch.bfloat16: 2.0 ** -9, torch.float16: 2.0 ** -12}
+
+
+def error_bound(out: torch.Tensor, out_abs_v: torch.Tensor) -> torch.Tensor:
+    """Elementwise tolerance for an attention output: ``out`` is the oracle's result, ``out_abs_v`` the oracle's
+    result with V replaced by |V| (= sum_j p_j |v_j|)."""
+    u = UNIT_ROUNDOFF[out.dtype]
+    return 3.0 * u * out_abs_v.float() + 4.0 * u * out.float().abs()
+
+
+def check_close(got: torch.Tensor, want: torch.Tensor, want_abs_v: torch.Tensor, what: str = "attention") -> None:
+    """Assert ``got`` (kernel) against ``want`` (oracle): the elementwise bound above, and an rms error below 1 % of
+    the output's rms (bf16; 0.15 % fp16) so that a whole missing 32-key chunk of a 1k-3k context cannot hide."""
+    got, wf = got.float().cpu(), want.float()
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - wf).abs()
+    tol = error_bound(want, want_abs_v)
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())} of {bad.numel()} elements beyond the rounding bound; worst "
+                           f"{err.max().item():.3e} vs bound {tol.flatten()[err.argmax()].item():.3e}")
+    rms_o = wf.pow(2).mean().sqrt().item()
+    if rms_o > 0:
+        ratio = err.pow(2).mean().sqrt().item() / rms_o
+        assert ratio < (1e-2 if want.dtype == torch.bfloat16 else 1.5e-3), f"{what}: rms error {ratio:.2e} of rms(O)"

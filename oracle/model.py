@@ -100,9 +100,23 @@ def shard_merged(w, rank, size):
     return torch.cat([gate.chunk(size, 0)[rank], up.chunk(size, 0)[rank]], dim=0)
 
 
+class _Upcast:
+    """Read-only view of a checkpoint dict that converts each tensor to ``dtype`` when it is looked up, so a
+    high-precision run never holds a second copy of the whole model."""
+
+    def __init__(self, weights, dtype):
+        self.weights, self.dtype = weights, dtype
+
+    def __getitem__(self, name):
+        return self.weights[name].to(self.dtype)
+
+
 class OracleQwen:
-    def __init__(self, cfg, weights, block_size, num_blocks, tp_size=1):
-        self.cfg, self.w = cfg, weights
+    def __init__(self, cfg, weights, block_size, num_blocks, tp_size=1, compute_dtype=None):
+        """compute_dtype=torch.float64: the same graph on the same (16-bit-valued) weights with every intermediate
+        kept in high precision: the yardstick two 16-bit implementations are measured against.  (The reference's
+        own fp32 run is no such yardstick: in fp32 its add_rms_forward aliases the residual, see oracle/layers.py.)"""
+        self.cfg, self.w = cfg, weights if compute_dtype is None else _Upcast(weights, compute_dtype)
         self.tp = tp_size
         self.block_size = block_size
         self.eps = cfg.rms_norm_eps
@@ -111,7 +125,7 @@ class OracleQwen:
         assert cfg.num_attention_heads % tp_size == 0 and cfg.num_key_value_heads % tp_size == 0
         self.d = cfg.head_dim
         self.bias = getattr(cfg, "attention_bias", True)
-        dtype = weights["model.norm.weight"].dtype
+        dtype = compute_dtype or weights["model.norm.weight"].dtype
         self.cos_sin = L.build_cos_sin_cache(self.d, cfg.max_position_embeddings, cfg.rope_theta)
         # model_runner.py:137-144: [2, L, NB, bs, Hkv/tp, D], one per simulated rank
         self.kv = [torch.zeros(2, cfg.num_hidden_layers, num_blocks, block_size, self.hkv, self.d, dtype=dtype)

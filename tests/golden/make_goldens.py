@@ -167,7 +167,7 @@ def gen_model():
     out = {}
     bs, nb = 16, 12
     for style in ("qwen2", "qwen3"):
-        for dname in ("fp32", "bf16"):
+        for dname in ("fp32", "bf16", "fp16"):
             dt = DT[dname]
             cfg = tiny_cfg(style, dt)
             weights = OM.random_weights(cfg, seed=7)

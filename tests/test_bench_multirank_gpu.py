@@ -12,13 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["dp", "tp"])
+@pytest.mark.parametrize("mode", ["dp", "default"])
 def test_bench_two_ranks(mode):
+    """`default` passes no --parallelism, as the round driver does: with more than one rank that is the tensor-parallel
+    split (one model over both ranks, all-reduce on the data path) plus the replicas leg."""
     env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533" if mode == "dp" else "29534",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--workload", "qwen2-0.5b-fp16-b1-s128", "--parallelism", mode]
+           "--workload", "qwen2-0.5b-fp16-b1-s128"] + (["--parallelism", "dp"] if mode == "dp" else [])
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -26,5 +28,7 @@ def test_bench_two_ranks(mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
     assert d["scaling"] == ("weak" if mode == "dp" else "strong")
-    assert d["config"]["parallelism"] == f"{mode}2"
+    assert d["config"]["parallelism"] == ("dp2" if mode == "dp" else "tp2")
+    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert ("replicas_tok_s" in d) == (mode != "dp") and d.get("replicas_tok_s", 1) > 0
     assert "cpu_baseline" not in d                      # rank 0 times the CPU baseline at N = 1 only

@@ -1,8 +1,17 @@
-"""The benchmark's own configuration at full size: Qwen2-0.5B geometry, int4 weights, 128 sequences, context 1024.
+"""The benchmark's workloads at their own sizes.
 
-The CPU oracle cannot run 128 x 1024 in seconds, so the batch is checked through properties that do not depend on
-its size (row permutation, graph replay == eager, padding rows inert) and through the oracle on a SAMPLE of the rows,
-which works because every row of a decode step is independent of the others.
+    0.5b-w4a16-b128   Qwen2-0.5B geometry, int4 weights, 128 sequences, context ~1024 (the headline configuration)
+    7b-w4a16-b128     Qwen2-7B layer geometry (h 3584, 28/4 heads of 128, intermediate 18944), int4, 128 sequences:
+                      the GEMM instantiations a 7B step runs (3 and 2 tiles per wavefront, split-K 9, the split-K
+                      q/k/v projection + RoPE pair) and the D=128 attention kernel.  Two decoder layers and a 32 k
+                      vocabulary instead of 28 and 152 k: every layer repeats the same launches, and the LM head
+                      at its real shape is covered by tests/test_kernels_gpu.py::test_gemm_qwen2_7b_shapes.
+    0.5b-bf16-b32     Qwen2-0.5B dense bf16, 32 sequences
+    0.5b-w8a16-b64    Qwen2-0.5B int8 weights, 64 sequences
+
+The CPU oracle cannot run 128 x 1024 in seconds, so a batch is checked through properties that do not depend on its
+size (row permutation, graph replay == eager, padding rows inert) and, for the two int4 workloads, through the oracle
+on a SAMPLE of the rows, which works because every row of a decode step is independent of the others.
 """
 
 import random
@@ -14,41 +23,56 @@ from oracle import model as OM
 
 pytestmark = pytest.mark.gpu
 
-BATCH, CONTEXT, BLOCK = 128, 1024, 256
+CONTEXT, BLOCK = 1024, 256
+WORKLOADS = {
+    # name: (geometry, config overrides, quantization, batch, CPU weights for the oracle?)
+    "0.5b-w4a16-b128": ("qwen2-0.5b", {}, "w4a16", 128, True),
+    "7b-w4a16-b128": ("qwen2-7b", dict(num_hidden_layers=2, vocab_size=32768), "w4a16", 128, True),
+    "0.5b-bf16-b32": ("qwen2-0.5b", {}, None, 32, False),
+    "0.5b-w8a16-b64": ("qwen2-0.5b", {}, "w8a16", 64, False),
+}
 
 
-@pytest.fixture(scope="module")
-def full():
+class Full:
+    pass
+
+
+@pytest.fixture(scope="module", params=list(WORKLOADS))
+def full(request):
     from byox_vllm_amd.config import Config, qwen2_config
     from byox_vllm_amd.engine.model_runner import ModelRunner
     from byox_vllm_amd.layers.rotary_embedding import get_rope
+    geometry, overrides, quant, batch, with_oracle = WORKLOADS[request.param]
     get_rope.cache_clear()
-    hf = qwen2_config("qwen2-0.5b", dtype=torch.bfloat16)
-    weights = OM.random_weights(hf, seed=0)
+    f = Full()
+    f.name, f.batch, f.quant = request.param, batch, quant
+    f.hf = qwen2_config(geometry, dtype=torch.bfloat16, **overrides)
+    f.weights = OM.random_weights(f.hf, seed=0) if with_oracle else None
     blocks_per_seq = CONTEXT // BLOCK + 1
-    runners = {}
+    f.runners = {}
     for eager in (True, False):
-        config = Config("synthetic", hf_config=hf, state_dict=weights, quantization="w4a16", kvcache_block_size=BLOCK,
-                        num_kvcache_blocks=BATCH * blocks_per_seq + 1, max_model_len=blocks_per_seq * BLOCK,
-                        max_num_seqs=BATCH, max_num_batched_tokens=8192, enforce_eager=eager, graph_batch_sizes=[BATCH])
-        runners[eager] = ModelRunner(config, 0, None)
-    g = torch.Generator(device="cpu").manual_seed(5)
-    history = torch.randn(runners[True].kv_cache.shape, generator=g, dtype=torch.float32).to(torch.bfloat16)
-    for r in runners.values():
-        r.kv_cache.copy_(history)
-    yield hf, weights, runners, history
-    for r in runners.values():
+        config = Config("synthetic", hf_config=f.hf, state_dict=f.weights, quantization=quant, kvcache_block_size=BLOCK,
+                        num_kvcache_blocks=batch * blocks_per_seq + 1, max_model_len=blocks_per_seq * BLOCK,
+                        max_num_seqs=batch, max_num_batched_tokens=8192, enforce_eager=eager, graph_batch_sizes=[batch],
+                        seed=3)
+        f.runners[eager] = ModelRunner(config, 0, None)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    f.history = torch.randn(f.runners[True].kv_cache.shape, generator=g, device="cuda", dtype=torch.bfloat16)
+    yield f
+    for r in f.runners.values():
         r.exit()
+    del f.runners, f.history
+    torch.cuda.empty_cache()
     get_rope.cache_clear()
 
 
-def make_seqs(order=None, temperature=0.0):
+def make_seqs(batch, order=None, temperature=0.0):
     from byox_vllm_amd.engine.sequence import Sequence
     from byox_vllm_amd.sampling_params import SamplingParams
     rng = random.Random(0)
     per = CONTEXT // BLOCK + 1
     seqs = []
-    for i in range(BATCH):
+    for i in range(batch):
         n = CONTEXT - (i % 7) * 37          # ragged contexts, 802..1024
         s = Sequence([rng.randrange(10000) for _ in range(n)], BLOCK,
                      SamplingParams(temperature=temperature, max_tokens=1 << 20, ignore_eos=True))
@@ -59,77 +83,123 @@ def make_seqs(order=None, temperature=0.0):
 
 def test_graph_and_eager_agree_and_rows_permute(full):
     """Greedy tokens: hipGraph replay == eager launch, and shuffling the rows of the batch shuffles the tokens."""
-    _, _, runners, history = full
-    base = runners[True].run(make_seqs(), False)
-    assert len(base) == BATCH and len(set(base)) > 1
-    runners[False].kv_cache.copy_(history)
-    assert runners[False].run(make_seqs(), False) == base
-    order = list(range(BATCH))
+    eager, graph = full.runners[True], full.runners[False]
+    eager.kv_cache.copy_(full.history)
+    base = eager.run(make_seqs(full.batch), False)
+    assert len(base) == full.batch and len(set(base)) > 1
+    graph.kv_cache.copy_(full.history)
+    assert graph.run(make_seqs(full.batch), False) == base
+    order = list(range(full.batch))
     random.Random(1).shuffle(order)
-    runners[True].kv_cache.copy_(history)
-    shuffled = runners[True].run(make_seqs(order), False)
+    eager.kv_cache.copy_(full.history)
+    shuffled = eager.run(make_seqs(full.batch, order), False)
     assert shuffled == [base[i] for i in order]
 
 
 def test_partial_batch_pads_to_the_captured_size(full):
-    """101 live rows replayed through the 128-row graph return what the same rows return in the full batch: padding
-    rows are inert and no row depends on another.  (The eager step is no yardstick here: at 101 rows the GEMM planner
-    picks other tiles and split-K factors, so its sums round differently.)"""
-    _, _, runners, history = full
-    runners[False].kv_cache.copy_(history)
-    want = runners[False].run(make_seqs(), False)[:101]
-    runners[False].kv_cache.copy_(history)
-    assert runners[False].run(make_seqs()[:101], False) == want
+    """A partial batch replayed through the full-size graph returns what the same rows return in the full batch:
+    padding rows are inert and no row depends on another.  (The eager step is no yardstick here: at fewer rows the
+    GEMM planner picks other tiles and split-K factors, so its sums round differently.)"""
+    graph = full.runners[False]
+    live = full.batch - full.batch // 5 - 1
+    graph.kv_cache.copy_(full.history)
+    want = graph.run(make_seqs(full.batch), False)[:live]
+    graph.kv_cache.copy_(full.history)
+    assert graph.run(make_seqs(full.batch)[:live], False) == want
+
+
+def test_graph_without_head_matches_graph_with_head(full):
+    """The forward-only graph (what a tensor-parallel rank replays: staging kernel -> graph -> LM head, gather and
+    sampler outside, model_runner.py:246-254 of the reference) gives the tokens of the single-rank graph that ends
+    in the sampler."""
+    from byox_vllm_amd.config import Config
+    from byox_vllm_amd.engine.model_runner import ModelRunner
+    if full.name != "0.5b-w4a16-b128":
+        pytest.skip("one workload is enough for the runner's dispatch")
+    blocks_per_seq = CONTEXT // BLOCK + 1
+    config = Config("synthetic", hf_config=full.hf, state_dict=full.weights, quantization=full.quant,
+                    kvcache_block_size=BLOCK, num_kvcache_blocks=full.batch * blocks_per_seq + 1,
+                    max_model_len=blocks_per_seq * BLOCK, max_num_seqs=full.batch, max_num_batched_tokens=8192,
+                    enforce_eager=False, graph_batch_sizes=[full.batch], graph_head=False, seed=3)
+    runner = ModelRunner(config, 0, None)
+    try:
+        assert not runner.graph_has_head and runner.graphs
+        replays = []
+        real = runner._replay
+        runner._replay = lambda bs: (replays.append(bs), real(bs))[1]
+        full.runners[False].kv_cache.copy_(full.history)
+        want = full.runners[False].run(make_seqs(full.batch), False)
+        for live in (full.batch, full.batch - 27):
+            runner.kv_cache.copy_(full.history)
+            assert runner.run(make_seqs(full.batch)[:live], False) == want[:live]
+        assert replays == [full.batch, full.batch], "the forward-only graph must have been replayed, not the eager path"
+    finally:
+        runner.exit()
+
+
+def _errors(x, truth):
+    e = (x.double() - truth.double()).abs()
+    return e.max().item(), e.pow(2).mean().sqrt().item()
 
 
 def test_sampled_rows_match_the_oracle(full):
-    """Rows 0, 77 and 127 of the full batch against the CPU oracle run on those three sequences alone."""
+    """Three rows of the full batch against the CPU oracle run on those three sequences alone.
+
+    The bound is derived, not chosen: the oracle runs twice on the same (dequantised) weights, once in bf16 like the
+    reference and once with every intermediate in fp64 (the truth).  The reference-style bf16 run sits some distance
+    from the truth after all its layers of rounding; the HIP step may sit at most 1.5 times as far (max and rms over
+    the logits; for the few hundred K/V values appended to the cache, 1.5 x rms and 2 x max)."""
     from byox_vllm_amd.utils.context import reset_context, set_context
-    hf, weights, runners, history = full
-    runner = runners[True]
-    runner.kv_cache.copy_(history)
-    seqs = make_seqs()
-    rows = [0, 77, 127]
-    # product: logits of the whole batch through the eager model
+    if full.weights is None:
+        pytest.skip("property checks only for this workload")
+    hf, weights, batch = full.hf, full.weights, full.batch
+    runner = full.runners[True]
+    runner.kv_cache.copy_(full.history)
+    seqs = make_seqs(batch)
+    rows = [0, batch * 3 // 5, batch - 1]
     lens = [len(s) for s in seqs]
     ctx, pos = OM.decode_ctx(lens, [s.block_table for s in seqs], BLOCK)
     ids = torch.tensor([s.last_token for s in seqs])
     d = lambda x: None if x is None else x.to(runner.device)  # noqa: E731
     set_context(False, None, None, 0, 0, d(ctx.slot_mapping), d(ctx.context_lens), d(ctx.block_tables))
-    runner._set_decode_splits(BATCH)
+    runner._set_decode_splits(batch)
     with torch.inference_mode():
         got = runner.model.compute_logits(runner.model(d(ids), d(pos))).float().cpu()
     reset_context()
     # oracle: the same three sequences with their history blocks copied into a small cache
     per = CONTEXT // BLOCK + 1
-    om = OM.OracleQwen(hf, OM.fake_quantize(weights, 4), BLOCK, len(rows) * per)
-    tables = []
+    qw = OM.fake_quantize(weights, 4 if full.quant == "w4a16" else 8)
+    outs, caches, tables = {}, {}, []
     for j, i in enumerate(rows):
         tables.append(list(range(j * per, j * per + len(seqs[i].block_table))))
-        om.kv[0][:, :, tables[j]] = history[:, :, seqs[i].block_table]
     octx, opos = OM.decode_ctx([lens[i] for i in rows], tables, BLOCK)
-    want = om.compute_logits(om.forward(ids[rows], opos, octx), octx).float()
-    err = got[rows] - want
-    rms, worst = err.pow(2).mean().sqrt().item(), err.abs().max().item()
-    print(f"full-size logits vs oracle: rms {rms:.4f} max {worst:.4f}; |logit| max {want.abs().max().item():.2f} "
-          f"std {want.std().item():.3f}")
-    # Two bf16 implementations with different summation orders drift apart by one rounding (2^-9 relative) per
-    # operation; over 24 layers of ~8 operations that random walk is a few percent of the logit spread.  Measured:
-    # rms 0.024 = 4 % of the logit std 0.60, worst of 456 k logits 0.14.  The 2-layer goldens hold 4e-2 absolute.
-    assert rms < 0.04
-    assert worst < 0.25
-    top2 = want.topk(2, dim=-1).values
+    for mode, cdt in (("bf16", None), ("truth", torch.float64)):
+        om = OM.OracleQwen(hf, qw, BLOCK, len(rows) * per, compute_dtype=cdt)
+        for j, i in enumerate(rows):
+            om.kv[0][:, :, tables[j]] = full.history[:, :, seqs[i].block_table].cpu().to(om.kv[0].dtype)
+        outs[mode] = om.compute_logits(om.forward(ids[rows], opos, octx), octx)
+        caches[mode] = om.kv[0]
+    truth = outs["truth"]
+    hip_max, hip_rms = _errors(got[rows], truth)
+    ref_max, ref_rms = _errors(outs["bf16"], truth)
+    print(f"{full.name}: logits vs fp64 truth: hip max {hip_max:.4f} rms {hip_rms:.5f} | bf16 oracle max {ref_max:.4f} "
+          f"rms {ref_rms:.5f} | logit std {truth.std().item():.3f}")
+    assert hip_rms <= 1.5 * ref_rms and hip_max <= 1.5 * ref_max
+    top2 = truth.topk(2, dim=-1).values
     for j in range(len(rows)):
-        if (top2[j, 0] - top2[j, 1]).item() > 0.25:
-            assert got[rows[j]].argmax().item() == want[j].argmax().item()
-    # the K/V rows the step appended to the paged cache (layer 0 and the last layer) equal the oracle's
-    for j, i in enumerate(rows):
-        t = lens[i] - 1
-        for layer in (0, hf.num_hidden_layers - 1):
-            mine = runner.kv_cache[:, layer, seqs[i].block_table[t // BLOCK], t % BLOCK].float().cpu()
-            theirs = om.kv[0][:, layer, tables[j][t // BLOCK], t % BLOCK].float()
-            d = (mine - theirs).abs()
-            if layer == 0:      # one norm and one GEMM away from the embedding: a rounding or two
-                assert d.max().item() < 2e-2
-            else:               # 23 layers of accumulated bf16 rounding, same budget as the logits above
-                assert d.max().item() < 0.25 and d.pow(2).mean().sqrt().item() < 0.04
+        if (top2[j, 0] - top2[j, 1]).item() > 2 * hip_max:
+            assert got[rows[j]].argmax().item() == truth[j].argmax().item()
+    # the K/V rows the step appended to the paged cache (layer 0 and the last layer)
+    for layer in (0, hf.num_hidden_layers - 1):
+        mine, ref, tru = [], [], []
+        for j, i in enumerate(rows):
+            t = lens[i] - 1
+            mine.append(runner.kv_cache[:, layer, seqs[i].block_table[t // BLOCK], t % BLOCK].float().cpu())
+            ref.append(caches["bf16"][:, layer, tables[j][t // BLOCK], t % BLOCK].float())
+            tru.append(caches["truth"][:, layer, tables[j][t // BLOCK], t % BLOCK])
+        mine, ref, tru = torch.stack(mine), torch.stack(ref), torch.stack(tru)
+        assert tru.abs().max().item() > 0
+        (m_max, m_rms), (r_max, r_rms) = _errors(mine, tru), _errors(ref, tru)
+        print(f"{full.name}: layer {layer} K/V rows vs truth: hip max {m_max:.4f} rms {m_rms:.5f} | bf16 oracle "
+              f"max {r_max:.4f} rms {r_rms:.5f}")
+        assert m_rms <= 1.5 * r_rms and m_max <= 2.0 * r_max

@@ -9,7 +9,6 @@ from oracle import attention as OA
 
 pytestmark = pytest.mark.gpu
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
-TOL = {"bf16": 2e-2, "fp16": 3e-3}
 HEADS = [(14, 2), (28, 4), (16, 8), (4, 4), (8, 1), (6, 2), (16, 1)]   # groups of 7, 7, 2, 1, 8, 3, 16
 EDGES = [1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513]
 
@@ -41,6 +40,7 @@ def test_fuzz_prefill_attention(seed):
         v = torch.randn(T, Hkv, D, generator=g).to(dt)
         cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
         want = OA.attn_varlen(q, k, v, cu, cu, D ** -0.5)
+        want_abs = OA.attn_varlen(q, k, v.abs(), cu, cu, D ** -0.5)
         got = kernels.attn_prefill(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(lens), D ** -0.5)
     else:   # prefix-cache prefill: the last q_len tokens of each sequence attend to the whole paged sequence
         bs = int(rng.choice([16, 32, 256]))
@@ -60,12 +60,13 @@ def test_fuzz_prefill_attention(seed):
         q = torch.randn(sum(q_lens), H, D, generator=g).to(dt)
         cu_q = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
         cu_k = torch.tensor([0] + list(np.cumsum(k_lens)), dtype=torch.int32)
+        vc_abs = vc.abs()
+        vc_abs[-1] = float("nan")
         want = OA.attn_varlen(q, kc, vc, cu_q, cu_k, D ** -0.5, tables)
+        want_abs = OA.attn_varlen(q, kc, vc_abs, cu_q, cu_k, D ** -0.5, tables)
         got = kernels.attn_prefill(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(q_lens), D ** -0.5,
                                    block_tables=dev(tables))
-    got = got.float().cpu()
-    assert torch.isfinite(got).all()
-    assert (got - want.float()).abs().max().item() <= TOL[name]
+    OA.check_close(got, want, want_abs, f"fuzz prefill seed {seed}")
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -96,11 +97,10 @@ def test_fuzz_paged_decode_attention(seed):
     q = torch.randn(B, H, D, generator=g).to(dt)
     ctx = torch.tensor(lens, dtype=torch.int32)
     want = OA.paged_attn_decode(q, kc, vc, ctx, tables, D ** -0.5)
+    want_abs = OA.paged_attn_decode(q, kc, vc.abs(), ctx, tables, D ** -0.5)
     for splits in (1, int(rng.randint(2, 6))):
-        got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5,
-                                        num_splits=splits).float().cpu()
-        assert torch.isfinite(got).all()
-        assert (got - want.float()).abs().max().item() <= TOL[name], (splits, lens)
+        got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5, num_splits=splits)
+        OA.check_close(got, want, want_abs, f"fuzz decode seed {seed} splits {splits} lens {lens}")
 
 
 @pytest.mark.parametrize("seed", range(16))

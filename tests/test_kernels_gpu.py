@@ -153,11 +153,13 @@ def _paged_case(B, H, Hkv, D, bs, lens, dt, seed=0, extra_cols=2):
     return q, kc, vc, torch.tensor(lens, dtype=torch.int32), tables
 
 
-ATTN_TOL = {"bf16": 2e-2, "fp16": 3e-3}   # |O| <= ~4 here; P is rounded to the model dtype before P.V (as flash-attn does)
+def _decode_oracle(q, kc, vc, ctx, tables, scale):
+    """-> (oracle output, oracle output with |V|: the sum_j p_j |v_j| the rounding bound is built from)."""
+    return (OA.paged_attn_decode(q, kc, vc, ctx, tables, scale),
+            OA.paged_attn_decode(q, kc, vc.abs(), ctx, tables, scale))
 
 
-@pytest.mark.parametrize("name", list(DT))
-@pytest.mark.parametrize("cfg", [
+PAGED_CASES = [
     dict(B=5, H=14, Hkv=2, D=64, bs=16, lens=[1, 16, 17, 100, 257]),        # Qwen2-0.5B heads, tiny blocks, ragged
     dict(B=3, H=28, Hkv=4, D=128, bs=256, lens=[255, 256, 700]),            # Qwen2-7B heads, production block size
     dict(B=4, H=16, Hkv=8, D=128, bs=32, lens=[31, 32, 33, 64]),            # Qwen3-0.6B heads
@@ -166,32 +168,99 @@ ATTN_TOL = {"bf16": 2e-2, "fp16": 3e-3}   # |O| <= ~4 here; P is rounded to the 
     dict(B=7, H=14, Hkv=2, D=64, bs=256, lens=[1023, 1024, 1025, 1061, 2047, 3000, 33]),   # bench-sized contexts:
     dict(B=4, H=28, Hkv=4, D=128, bs=256, lens=[1024, 1057, 2049, 31]),     # every wavefront runs its chunk rotation
     dict(B=2, H=8, Hkv=2, D=128, bs=16, lens=[515, 258]),                   # zero-padded query slots (group 4 of 16)
-])
+]
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("cfg", PAGED_CASES)
 @pytest.mark.parametrize("splits", [1, 2, 5])
 def test_paged_decode_attention(name, cfg, splits):
     from byox_vllm_amd import kernels
     dt = DT[name]
     q, kc, vc, ctx, tables = _paged_case(dt=dt, **cfg)
-    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
     got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5,
                                     num_splits=splits)
-    err = (got.float().cpu() - want.float()).abs().max().item()
-    assert err <= ATTN_TOL[name], err
-    assert torch.isfinite(got.float()).all()
+    OA.check_close(got, want, want_abs, f"paged decode splits={splits}")
+
+
+@pytest.mark.parametrize("waves", ["4", "8", "16"])
+@pytest.mark.parametrize("cfg", [PAGED_CASES[0], PAGED_CASES[5], PAGED_CASES[6], PAGED_CASES[7]])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_paged_decode_forced_wavefront_counts(cfg, waves, splits, monkeypatch):
+    """Every compiled workgroup size of the decode kernel (4, 8, 16 wavefronts; 16 exists at D=64 only and falls
+    back to 8 at D=128) is the same function."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_ATTN_WAVES", waves)
+    q, kc, vc, ctx, tables = _paged_case(dt=torch.bfloat16, **cfg)
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5,
+                                    num_splits=splits)
+    OA.check_close(got, want, want_abs, f"paged decode waves={waves} splits={splits}")
+
+
+@pytest.mark.parametrize("D,H,Hkv", [(64, 14, 2), (128, 28, 4)])
+@pytest.mark.parametrize("n", [1024, 3000])
+@pytest.mark.parametrize("splits", [1, 4])
+def test_paged_decode_single_chunk_mutation(D, H, Hkv, n, splits):
+    """Zero the V rows of ONE interior 32-key chunk: the kernel's output must move exactly as the oracle's does.
+    A kernel that skipped that chunk (or any other: see the census test below) cannot pass."""
+    from byox_vllm_amd import kernels
+    q, kc, vc, ctx, tables = _paged_case(B=1, H=H, Hkv=Hkv, D=D, bs=256, lens=[n], dt=torch.bfloat16, seed=n + D)
+    scale = D ** -0.5
+    chunk = (n // 32) // 2 + 3                                  # an interior chunk, not aligned to a block start
+    vc2 = vc.clone()
+    for tok in range(32 * chunk, 32 * chunk + 32):
+        vc2[tables[0, tok // 256].item(), tok % 256] = 0
+    want0, abs0 = _decode_oracle(q, kc, vc, ctx, tables, scale)
+    want1, abs1 = _decode_oracle(q, kc, vc2, ctx, tables, scale)
+    run = lambda v: kernels.paged_attn_decode(dev(q), dev(kc), dev(v), dev(ctx), dev(tables), scale, num_splits=splits)  # noqa: E731
+    got0, got1 = run(vc), run(vc2)
+    OA.check_close(got0, want0, abs0, "before the mutation")
+    OA.check_close(got1, want1, abs1, "after the mutation")
+    moved_want = (want1.float() - want0.float())
+    moved_got = (got1.float() - got0.float()).cpu()
+    assert moved_want.abs().max().item() > 0
+    # the oracle's own movement carries two bf16 output roundings; the kernel's must match it to that accuracy
+    resid = (moved_got - moved_want).pow(2).mean().sqrt().item()
+    assert resid < 0.35 * moved_want.pow(2).mean().sqrt().item(), (resid, moved_want.pow(2).mean().sqrt().item())
+
+
+@pytest.mark.parametrize("D,H,Hkv", [(64, 14, 2), (128, 28, 4)])
+@pytest.mark.parametrize("n", [1024, 1999, 3000])
+@pytest.mark.parametrize("splits", [1, 2, 5])
+@pytest.mark.parametrize("waves", ["4", "8", "16"])
+def test_paged_decode_chunk_census(D, H, Hkv, n, splits, waves, monkeypatch):
+    """V marks every 32-key chunk with its own output dimension (V[token, d] = 1 iff d == chunk % D), so O[d] is the
+    softmax mass of the chunks mapped to d: a chunk that is skipped, read twice or read from the wrong rows shows up
+    as a missing or doubled mass in its own dimension."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_ATTN_WAVES", waves)
+    q, kc, vc, ctx, tables = _paged_case(B=2, H=H, Hkv=Hkv, D=D, bs=256, lens=[n, n - 77], dt=torch.bfloat16, seed=n)
+    q = (q * 0.25).to(torch.bfloat16)          # flatter softmax: every chunk keeps a mass far above the rounding bound
+    vc.zero_()
+    for b, nb in enumerate([n, n - 77]):
+        tok = torch.arange(nb)
+        for h in range(Hkv):
+            vc[tables[b, tok // 256].long(), tok % 256, h, (tok // 32) % D] = 1.0
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, D ** -0.5)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5, num_splits=splits)
+    OA.check_close(got, want, want_abs, "chunk census")
+    assert (want.float() > 0).any()
+    assert torch.allclose(got.float().cpu().sum(-1), torch.ones(2, H), atol=2e-2)   # masses sum to one
 
 
 def test_paged_decode_ignores_garbage_past_context():
     """Slots past the context length may hold NaN/Inf bit patterns (recycled blocks): they must not leak."""
     from byox_vllm_amd import kernels
     q, kc, vc, ctx, tables = _paged_case(B=2, H=14, Hkv=2, D=64, bs=16, lens=[19, 35], dt=torch.bfloat16)
-    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, 0.125)
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, 0.125)
     for b, n in enumerate([19, 35]):
         blk, off = tables[b, n // 16].item(), n % 16
         kc[blk, off:] = float("nan")
         vc[blk, off:] = float("inf")
     got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), 0.125)
-    assert torch.isfinite(got.float()).all()
-    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+    OA.check_close(got, want, want_abs, "garbage past the context")
 
 
 def test_paged_decode_softmax_rescale_branch():
@@ -200,9 +269,9 @@ def test_paged_decode_softmax_rescale_branch():
     q, kc, vc, ctx, tables = _paged_case(B=1, H=14, Hkv=2, D=64, bs=16, lens=[200], dt=torch.bfloat16, seed=3)
     blk = tables[0, 150 // 16].item()
     kc[blk, 150 % 16] = (q[0, 0] * 6).to(torch.bfloat16)      # spike for head 0 at token 150
-    want = OA.paged_attn_decode(q, kc, vc, ctx, tables, 0.125)
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, 0.125)
     got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), 0.125)
-    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+    OA.check_close(got, want, want_abs, "rescale branch")
 
 
 @pytest.mark.parametrize("name", list(DT))
@@ -223,11 +292,11 @@ def test_prefill_attention_packed(name, cfg):
     v = qkv[:, (H + Hkv) * D:].view(T, Hkv, D)
     cu = torch.tensor([0] + list(np.cumsum(cfg["lens"])), dtype=torch.int32)
     want = OA.attn_varlen(q, k, v, cu, cu, D ** -0.5)
+    want_abs = OA.attn_varlen(q, k, v.abs(), cu, cu, D ** -0.5)
     qd = dev(qkv)
     got = kernels.attn_prefill(qd[:, : H * D].view(T, H, D), qd[:, H * D: (H + Hkv) * D].view(T, Hkv, D),
                                qd[:, (H + Hkv) * D:].view(T, Hkv, D), dev(cu), dev(cu), max(cfg["lens"]), D ** -0.5)
-    err = (got.float().cpu() - want.float()).abs().max().item()
-    assert err <= ATTN_TOL[name], err
+    OA.check_close(got, want, want_abs, "packed prefill")
 
 
 @pytest.mark.parametrize("qt", ["1", "2"])
@@ -249,9 +318,9 @@ def test_prefill_attention_query_tiles_per_wavefront(cfg, qt, monkeypatch):
     v = torch.randn(T, Hkv, D, generator=g).to(dt)
     cu = torch.tensor([0] + list(np.cumsum(cfg["lens"])), dtype=torch.int32)
     want = OA.attn_varlen(q, k, v, cu, cu, D ** -0.5)
+    want_abs = OA.attn_varlen(q, k, v.abs(), cu, cu, D ** -0.5)
     got = kernels.attn_prefill(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(cfg["lens"]), D ** -0.5)
-    err = (got.float().cpu() - want.float()).abs().max().item()
-    assert err <= ATTN_TOL["bf16"], err
+    OA.check_close(got, want, want_abs, f"prefill qt={qt}")
 
 
 def test_prefill_attention_prefix_cache_paged():
@@ -266,9 +335,10 @@ def test_prefill_attention_prefix_cache_paged():
     cu_q = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
     cu_k = torch.tensor([0] + list(np.cumsum(k_lens)), dtype=torch.int32)
     want = OA.attn_varlen(q, kc, vc, cu_q, cu_k, D ** -0.5, tables)
+    want_abs = OA.attn_varlen(q, kc, vc.abs(), cu_q, cu_k, D ** -0.5, tables)
     got = kernels.attn_prefill(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(q_lens), D ** -0.5,
                                block_tables=dev(tables))
-    assert (got.float().cpu() - want.float()).abs().max().item() <= ATTN_TOL["bf16"]
+    OA.check_close(got, want, want_abs, "prefix-cache prefill")
 
 
 GEMM_SHAPES = [(1, 128, 128), (7, 192, 256), (32, 1152, 896), (128, 896, 896), (130, 256, 384), (300, 64, 128)]
@@ -329,6 +399,126 @@ def test_gemm_many_rows(name, M, N, K, fmt):
     want = torch.nn.functional.linear(x.double(), w_ref.double(), bias.double())
     got = kernels.gemm(dev(x), lw, dev(bias))
     ulp_close(got, want.to(dt), name, ulps=1.0)
+
+
+def _weights_for(fmt, w):
+    """(kernel-side LinearWeight on the GPU, the oracle's dequantised reference weight on the CPU)."""
+    from byox_vllm_amd.layers.quant import LinearWeight
+    if fmt == "tiled":
+        return LinearWeight.dense_tiled(dev(w)), w
+    if fmt == "dense":
+        return LinearWeight.dense(dev(w)), w
+    if fmt == "w4a16":
+        return LinearWeight.make(dev(w), fmt), Q.dequantize_w4(*Q.quantize_w4(w))
+    return LinearWeight.make(dev(w), fmt), Q.dequantize_w8(*Q.quantize_w8(w))
+
+
+FORCED = [("w4a16", n) for n in (1, 2, 3)] + [("w8a16", n) for n in (1, 2, 3)] + \
+         [("tiled", n) for n in (1, 2)] + [("dense", n) for n in (1, 2)]
+
+
+@pytest.mark.parametrize("fmt,ntw", FORCED)
+@pytest.mark.parametrize("bm", ["16", "32", "64", "128"])
+@pytest.mark.parametrize("split_k", [1, 3, 9])
+def test_gemm_forced_tile_variants(fmt, ntw, bm, split_k, monkeypatch):
+    """Every compiled (weight format, tiles per wavefront, rows per workgroup) instantiation, with and without
+    split-K, is the same function: the planner normally picks among them by shape, here each one is forced on a
+    shape with ragged rows (130 = 8 x 16 + 2) and a ragged last column block (29 tiles of 16 columns)."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_GEMM_NTW", str(ntw))
+    monkeypatch.setenv("NV_GEMM_BM", bm)
+    M, N, K = 130, 464, 1152
+    g = torch.Generator().manual_seed(ntw * 100 + int(bm) + split_k)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+    lw, w_ref = _weights_for(fmt, w)
+    want = torch.nn.functional.linear(x.double(), w_ref.double(), bias.double())
+    got = kernels.gemm(dev(x), lw, dev(bias), split_k=split_k)
+    ulp_close(got, want.to(torch.bfloat16), "bf16", ulps=1.0)
+
+
+@pytest.mark.parametrize("fmt,ntw", [("w4a16", 1), ("w4a16", 2), ("w4a16", 3), ("w8a16", 3), ("tiled", 2)])
+@pytest.mark.parametrize("bm", ["16", "64", "128"])
+def test_gemm_forced_tile_variants_silu_epilogue(fmt, ntw, bm, monkeypatch):
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    monkeypatch.setenv("NV_GEMM_NTW", str(ntw))
+    monkeypatch.setenv("NV_GEMM_BM", bm)
+    M, K, inter = 130, 512, 232
+    g = torch.Generator().manual_seed(ntw + int(bm))
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inter, K, generator=g) * 0.05).to(torch.bfloat16)
+    _, w_ref = _weights_for(fmt, w)
+    wi = interleave_gate_up(dev(w))
+    lw = LinearWeight.dense_tiled(wi) if fmt == "tiled" else LinearWeight.make(wi, fmt)
+    want = L.silu_and_mul(L.linear(x, w_ref))
+    got = kernels.gemm(dev(x), lw, silu_mul=True)
+    assert got.shape == (M, inter)
+    ulp_close(got, want, "bf16", ulps=2.0)
+
+
+def _linear_fp64_rounded(x, w_ref, bias=None, rows=16384):
+    """F.linear in fp64 on the CPU, rounded once to the model dtype; W is walked in row slices to bound memory."""
+    xd = x.double()
+    outs = []
+    for lo in range(0, w_ref.size(0), rows):
+        b = None if bias is None else bias[lo: lo + rows].double()
+        outs.append(torch.nn.functional.linear(xd, w_ref[lo: lo + rows].double(), b).to(x.dtype))
+    return torch.cat(outs, dim=1)
+
+
+# the layer linears of Qwen2-7B (h 3584, q/k/v 3584 + 2 x 512, intermediate 18944) and its LM head, at the two batch
+# sizes the benchmark runs them with: the planner's own choices for these shapes (3 / 2 tiles per wavefront, split-K 9
+# for down_proj, 128-row tiles) are the kernels a 7B decode step spends its time in
+QWEN2_7B_LINEARS = [("qkv", 4608, 3584, "w4a16"), ("o", 3584, 3584, "w4a16"), ("down", 3584, 18944, "w4a16"),
+                    ("qkv", 4608, 3584, "w8a16"), ("down", 3584, 18944, "w8a16"), ("lm_head", 152064, 3584, "tiled")]
+
+
+@pytest.mark.parametrize("M", [128, 512])
+@pytest.mark.parametrize("which,N,K,fmt", QWEN2_7B_LINEARS)
+def test_gemm_qwen2_7b_shapes(which, N, K, fmt, M):
+    from byox_vllm_amd import kernels
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16) if which == "qkv" else None
+    lw, w_ref = _weights_for(fmt, w)
+    want = _linear_fp64_rounded(x, w_ref, bias)
+    got = kernels.gemm(dev(x), lw, None if bias is None else dev(bias))          # split-K and tiles: the planner's
+    ulp_close(got, want, "bf16", ulps=1.0)
+    if which in ("o", "down"):      # as the decode step runs them: slabs left for the next add-RMSNorm to sum
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16)
+        nw = (1 + 0.1 * torch.randn(N, generator=g)).to(torch.bfloat16)
+        parts = kernels.gemm(dev(x), lw, partial_out=True)
+        if isinstance(parts, kernels.Partials):
+            out, new_res = kernels.add_rms_norm(parts, dev(res), dev(nw), 1e-6)
+            # the fused consumer rounds the slab sum to bf16 first, exactly like the stand-alone GEMM did
+            want_out, want_res = L.add_rms_norm(got.cpu(), res, nw, 1e-6)
+            assert torch.equal(new_res.cpu(), want_res)
+            ulp_close(out, want_out, "bf16", ulps=1.0)
+
+
+@pytest.mark.parametrize("M", [128, 512])
+@pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
+def test_gemm_qwen2_7b_gate_up_silu(fmt, M):
+    """gate_up of Qwen2-7B (37888 x 3584) with the SiLU epilogue.  The oracle rounds gate and up to bf16 before the
+    activation; a gate that sits on a rounding boundary may land one ulp apart in two correct implementations, which
+    the activation and the product carry to the output: nearly all elements agree to 1 ulp, none is off by more than 4."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    K, inter = 3584, 18944
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(2 * inter, K, generator=g) * 0.02).to(torch.bfloat16)
+    w_ref = Q.dequantize_w4(*Q.quantize_w4(w)) if fmt == "w4a16" else Q.dequantize_w8(*Q.quantize_w8(w))
+    want = L.silu_and_mul(_linear_fp64_rounded(x, w_ref)).float()
+    got = kernels.gemm(dev(x), LinearWeight.make(interleave_gate_up(dev(w)), fmt), silu_mul=True).float().cpu()
+    assert got.shape == (M, inter)
+    err = (got - want).abs()
+    unit = EPS["bf16"] * want.abs().clamp_min(1e-3) * 2
+    assert (err > 4 * unit).sum().item() == 0, err.max().item()
+    assert (err > unit).float().mean().item() < 2e-3
 
 
 @pytest.mark.parametrize("M", [640, 2100])

@@ -11,10 +11,13 @@ pytestmark = pytest.mark.gpu
 BS = 16
 
 
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 def _golden_weights(golden, style, dname="bf16"):
     g = golden.npz("model")
     key = f"{style}_{dname}_"
-    dt = torch.bfloat16
+    dt = DT[dname]
     return g, key, {k[len(key) + 2:]: torch.from_numpy(g[k]).to(dt) for k in g.files if k.startswith(key + "w:")}
 
 
@@ -41,45 +44,74 @@ def forward(runner, ids, pos, ctx):
     return logits.float().cpu()
 
 
-# bf16 logits of magnitude ~1 carry 2^-8 relative rounding per op; over 2 layers two correct
-# implementations that differ only in summation order sit within a few 1e-2 of each other.
+# Absolute backstop only (bf16 logits of magnitude ~1 carry 2^-8 relative rounding per operation); the real bar is
+# relative to the reference's OWN 16-bit error, below.
 LOGIT_TOL = 4e-2
+ERROR_RATIO = 1.5   # HIP error vs the high-precision truth may be at most this multiple of the reference's own error
 
 
-@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
-def test_whole_model_vs_reference_goldens(golden, style):
-    """Prefill, 3 paged decode steps, prefix-cache prefill: logits against the reference's own (bf16)."""
-    g, key, weights = _golden_weights(golden, style)
-    cfg = OM.tiny_config(style, torch.bfloat16)
-    runner = make_runner(cfg, weights)
-    p0, p1 = g[key + "prompt0"].tolist(), g[key + "prompt1"].tolist()
-    ctx, pos = OM.prefill_ctx([5, 19], [[3], [7, 1]], BS)
-    logits = forward(runner, torch.tensor(p0 + p1), pos, ctx)
-    want = torch.from_numpy(g[key + "logits_prefill"])
-    assert (logits - want).abs().max().item() < LOGIT_TOL
-    assert logits.argmax(-1).tolist() == want.argmax(-1).tolist()
+def _phases(g, key):
+    """The golden run's steps: (name, input ids, lens, block tables, cached) in the order the reference ran them."""
+    p0, p1, p2 = (g[key + f"prompt{i}"].tolist() for i in range(3))
+    yield "prefill", torch.tensor(p0 + p1), [5, 19], [[3], [7, 1]], None
     lens, tables = [5, 19], [[3], [7, 1]]
     for step in range(3):
         lens = [n + 1 for n in lens]
         for tb, n in zip(tables, lens):
             if len(tb) * BS < n:
                 tb.append(9)
-        ctx, pos = OM.decode_ctx(lens, tables, BS)
-        logits = forward(runner, torch.from_numpy(g[key + f"decode{step}_in"]), pos, ctx)
-        want = torch.from_numpy(g[key + f"logits_decode{step}"])
-        assert (logits - want).abs().max().item() < LOGIT_TOL, step
-    p2 = g[key + "prompt2"].tolist()
-    ctx, pos = OM.prefill_ctx([22], [[7, 5]], BS, cached=[16])
-    logits = forward(runner, torch.tensor(p2[16:]), pos, ctx)
-    assert (logits - torch.from_numpy(g[key + "logits_prefix_prefill"])).abs().max().item() < LOGIT_TOL
-    # the paged KV cache holds exactly what the oracle's holds (k after RoPE, v verbatim)
+        yield f"decode{step}", torch.from_numpy(g[key + f"decode{step}_in"]), list(lens), [list(t) for t in tables], None
+    yield "prefix_prefill", torch.tensor(p2[16:]), [22], [[7, 5]], [16]
+
+
+@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_whole_model_vs_reference_goldens(golden, style, dname):
+    """Prefill, 3 paged decode steps, prefix-cache prefill against the reference's own 16-bit logits, judged by the
+    distance to a high-precision run of the same graph on the same weights (oracle, compute_dtype=float64):
+        max|hip - truth| <= 1.5 x max|reference - truth|   and   rms likewise,
+    i.e. the HIP path is as close to the exact result as the reference's own bf16/fp16 path is.  (The reference's
+    fp32 goldens cannot serve as that truth: in fp32 its add_rms_forward aliases the residual.)"""
+    g, key, weights = _golden_weights(golden, style, dname)
+    cfg = OM.tiny_config(style, DT[dname])
+    runner = make_runner(cfg, weights)
+    truth_model = OM.OracleQwen(cfg, weights, BS, 12, compute_dtype=torch.float64)
+    report = []
+    for name, ids, lens, tables, cached in _phases(g, key):
+        if name.startswith("decode"):
+            ctx, pos = OM.decode_ctx(lens, tables, BS)
+        else:
+            ctx, pos = OM.prefill_ctx(lens, tables, BS, cached=cached)
+        logits = forward(runner, ids, pos, ctx)
+        truth = truth_model.compute_logits(truth_model.forward(ids, pos, ctx), ctx).float()
+        ref = torch.from_numpy(g[key + "logits_" + name])
+        e_hip, e_ref = (logits - truth).abs(), (ref - truth).abs()
+        report.append((name, e_hip.max().item(), e_ref.max().item(), e_hip.pow(2).mean().sqrt().item(),
+                       e_ref.pow(2).mean().sqrt().item()))
+        assert e_hip.max().item() <= ERROR_RATIO * e_ref.max().item(), report[-1]
+        assert e_hip.pow(2).mean().sqrt().item() <= ERROR_RATIO * e_ref.pow(2).mean().sqrt().item(), report[-1]
+        assert (logits - ref).abs().max().item() < (LOGIT_TOL if dname == "bf16" else LOGIT_TOL / 8), name
+        if name == "prefill":
+            assert logits.argmax(-1).tolist() == ref.argmax(-1).tolist()
+    for row in report:
+        print("%s %s %-15s max hip %.4f ref %.4f | rms hip %.5f ref %.5f" % ((style, dname) + row))
+    # the paged KV cache holds what the oracle's holds (v = the projection's output: one GEMM away from the
+    # normalised embedding, so equal up to one rounding of the model dtype where the summation order matters)
     om = OM.OracleQwen(cfg, weights, BS, 12)
+    p0, p1 = g[key + "prompt0"].tolist(), g[key + "prompt1"].tolist()
     ctx, pos = OM.prefill_ctx([5, 19], [[3], [7, 1]], BS)
     om.forward(torch.tensor(p0 + p1), pos, ctx)
-    got_v = runner.kv_cache[1, 0].cpu()
+    runner2 = make_runner(cfg, weights)
+    forward(runner2, torch.tensor(p0 + p1), pos, ctx)
+    got_v = runner2.kv_cache[1, 0].cpu()
     blocks = [3, 7, 1]
-    assert torch.equal(got_v[blocks][:, :3], om.kv[0][1, 0][blocks][:, :3])
+    mine, theirs = got_v[blocks][:, :3].float(), om.kv[0][1, 0][blocks][:, :3].float()
+    assert theirs.abs().max().item() > 0
+    ulp = (2.0 ** -7 if dname == "bf16" else 2.0 ** -10) * theirs.abs().clamp_min(1e-3)
+    assert ((mine - theirs).abs() <= ulp).all()
+    assert (mine == theirs).float().mean().item() > 0.9
     runner.exit()
+    runner2.exit()
 
 
 @pytest.mark.parametrize("quant,bits", [("w8a16", 8), ("w4a16", 4)])

@@ -85,7 +85,7 @@ def load_tiny(golden, style, dname):
 
 
 @pytest.mark.parametrize("style", ["qwen2", "qwen3"])
-@pytest.mark.parametrize("dname", ["fp32", "bf16"])
+@pytest.mark.parametrize("dname", ["fp32", "bf16", "fp16"])
 def test_whole_model_bit_exact(golden, style, dname):
     """Prefill, 3 paged decode steps and a prefix-cache prefill: logits equal the reference's bit for bit."""
     g, key, cfg, weights = load_tiny(golden, style, dname)
@@ -130,3 +130,18 @@ def test_block_hash(golden):
         h.update(np.array(case["tokens"], dtype=np.int64).tobytes())
         assert h.intdigest() == case["hash"]
     assert golden.json("block_hash")[-1]["hash"] == 8040990501003754519
+
+
+@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
+@pytest.mark.parametrize("dname", ["bf16", "fp16"])
+def test_high_precision_mode_brackets_the_reference(golden, style, dname):
+    """compute_dtype=float64 runs the same graph on the same 16-bit weights without intermediate rounding: the
+    reference's 16-bit logits sit within a few roundings of it (and it has no fp32 residual-aliasing quirk)."""
+    g, key, cfg, weights = load_tiny(golden, style, dname)
+    m = OM.OracleQwen(cfg, weights, block_size=16, num_blocks=12, compute_dtype=torch.float64)
+    p0, p1 = g[key + "prompt0"].tolist(), g[key + "prompt1"].tolist()
+    ctx, pos = OM.prefill_ctx([5, 19], [[3], [7, 1]], 16)
+    truth = m.compute_logits(m.forward(torch.tensor(p0 + p1), pos, ctx), ctx)
+    assert truth.dtype == torch.float64
+    err = (torch.from_numpy(g[key + "logits_prefill"]).double() - truth).abs().max().item()
+    assert 0 < err < (4e-2 if dname == "bf16" else 6e-3)
