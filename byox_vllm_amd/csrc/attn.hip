@@ -1041,6 +1041,46 @@ extern "C" int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const v
                          workspace, workspace_bytes, B, H, Hkv, D, block_size, scale, num_splits, dtype, stream);
 }
 
+// ---- the same launch for callers that may not allocate: the split partials live in an array of the code object.
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process ends; the
+// name `static_scratch` is only a host-side handle, the device address comes from hipGetSymbolAddress, once per device.
+static __device__ __align__(256) unsigned char static_scratch[NV_PAGED_ATTN_STATIC_SCRATCH_BYTES];
+#define NV_MAX_DEVICES 64
+static void* static_scratch_ptr[NV_MAX_DEVICES];   // device address of static_scratch per device ordinal, 0 = not yet asked
+
+extern "C" int nv_paged_attn_decode_static(const void* q, int64_t q_row_stride, const void* k_cache,
+                                           const void* v_cache, const int32_t* block_tables, int bt_stride,
+                                           const int32_t* context_lens, void* out, int64_t out_row_stride, int B, int H,
+                                           int Hkv, int D, int block_size, float scale, int num_splits, int dtype,
+                                           nv_stream_t stream) {
+  if (num_splits <= 0) num_splits = 1;
+  NV_CHECK_ARG(B >= 0 && H > 0 && (D == 64 || D == 128), "nv_paged_attn_decode_static: bad shape B=%d H=%d D=%d", B, H, D);
+  const size_t need = nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits);
+  NV_CHECK_ARG(need <= (size_t)NV_PAGED_ATTN_STATIC_SCRATCH_BYTES,
+               "nv_paged_attn_decode_static: B=%d H=%d D=%d splits=%d need %zu bytes of split partials, the built-in "
+               "array holds %zu: use fewer splits or nv_paged_attn_decode with a caller workspace",
+               B, H, D, num_splits, need, (size_t)NV_PAGED_ATTN_STATIC_SCRATCH_BYTES);
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= NV_MAX_DEVICES) {
+    nv_set_error("nv_paged_attn_decode_static: no current device (or ordinal %d >= %d)", device, NV_MAX_DEVICES);
+    return NV_ERR_LAUNCH;
+  }
+  void* scratch = static_scratch_ptr[device];
+  if (!scratch) {   // first call on this device (make it outside stream capture): resolve this device's copy
+    const hipError_t e = hipGetSymbolAddress(&scratch, HIP_SYMBOL(static_scratch));
+    if (e != hipSuccess || !scratch) {
+      nv_set_error("nv_paged_attn_decode_static: hipGetSymbolAddress failed on device %d: %s", device, hipGetErrorString(e));
+      return NV_ERR_LAUNCH;
+    }
+    static_scratch_ptr[device] = scratch;
+  }
+  // nothing in the array has to start at zero: every (sequence, head, split) slot the combine kernel reads is
+  // written by this call's decode kernel first
+  return paged_decode_go(q, q_row_stride, k_cache, v_cache, block_tables, bt_stride, context_lens, out, out_row_stride,
+                         scratch, (size_t)NV_PAGED_ATTN_STATIC_SCRATCH_BYTES, B, H, Hkv, D, block_size, scale,
+                         num_splits, dtype, stream);
+}
+
 extern "C" int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* k, const void* v,
                                int64_t kv_row_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                const int32_t* block_tables, int bt_stride, void* out, int64_t out_row_stride,

@@ -163,6 +163,24 @@ def paged_attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale, ou
     return out
 
 
+def paged_attn_decode_static(q, k_cache, v_cache, context_lens, block_tables, scale, out, num_splits=1):
+    """paged_attn_decode through the entry point that allocates nothing: ``out`` is required and the split partials
+    live in the library's own per-GPU array (nv_paged_attn_decode_static)."""
+    require_gpu(q, "paged_attn_decode_static")
+    B, H, D = q.shape
+    nb, bs, hkv, d2 = k_cache.shape
+    assert d2 == D and q.stride(2) == 1 and q.stride(1) == D and out.shape == q.shape
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and v_cache.shape == k_cache.shape
+    assert context_lens.dtype == torch.int32 and context_lens.numel() == B and context_lens.is_contiguous()
+    assert block_tables.dtype == torch.int32 and block_tables.dim() == 2 and block_tables.size(0) >= B
+    assert block_tables.stride(1) == 1 and out.stride(2) == 1 and out.stride(1) == D
+    check(lib().nv_paged_attn_decode_static(ptr(q), q.stride(0), ptr(k_cache), ptr(v_cache), ptr(block_tables),
+                                            block_tables.stride(0), ptr(context_lens), ptr(out), out.stride(0),
+                                            B, H, hkv, D, bs, scale, num_splits, dtype_code(q.dtype), stream()),
+          "nv_paged_attn_decode_static")
+    return out
+
+
 def attn_prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scale, block_tables=None, out=None):
     """Causal varlen attention.  Packed k/v [Tk, Hkv, D] or, with block_tables, paged caches [NB, bs, Hkv, D]."""
     require_gpu(q, "attn_prefill")

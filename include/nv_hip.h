@@ -112,6 +112,19 @@ int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cach
                          int B, int H, int Hkv, int D, int block_size, float scale, int num_splits,
                          int dtype, nv_stream_t stream);
 
+/* nv_paged_attn_decode for callers that cannot allocate device memory (code under hipGraph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments without the workspace:
+ * the split partials go to an array built into the library, NV_PAGED_ATTN_STATIC_SCRATCH_BYTES per GPU, held until
+ * the process ends.  Requests that need more (nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits)) are
+ * rejected with NV_ERR_INVALID.  Calls no allocating routine.  All calls on one GPU share that GPU's array: calls
+ * that overlap on one GPU (two streams, two threads) race; calls on one stream are ordered and safe.  The first
+ * call on a device looks the array's address up (hipGetSymbolAddress): make it outside stream capture. */
+#define NV_PAGED_ATTN_STATIC_SCRATCH_BYTES (16u << 20)
+int nv_paged_attn_decode_static(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
+                                const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
+                                void* out, int64_t out_row_stride, int B, int H, int Hkv, int D, int block_size,
+                                float scale, int num_splits, int dtype, nv_stream_t stream);
+
 /* flash_attn_varlen_func as called at nanovllm/layers/attention.py:75-86:
  * causal (bottom-right aligned) variable-length prefill.
  * q [Tq, H, D]; without block_tables k/v are packed [Tk, Hkv, D] (row strides
