@@ -5,6 +5,17 @@
 
 #define GEMM_BK 128
 
+// Diagnostic build only (scripts/micro/gemm_probe.hip): cycle stamps per wavefront, written to the `partial` buffer.
+#ifdef NV_STAMP
+#define STAMP_DECL uint64_t st_t0 = __builtin_amdgcn_s_memtime(), st_a = 0, st_sumA = 0, st_sumBar = 0, st_sumB = 0, st_t1 = 0, st_t2 = 0
+#define STAMP(var) var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(sum, since) do { const uint64_t now_ = __builtin_amdgcn_s_memtime(); sum += now_ - since; since = now_; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(var)
+#define STAMP_ADD(sum, since)
+#endif
+
 // 8 weights of one lane's fragment -> model dtype, from 8 int4 nibbles (one dword).
 // Two masks spread the nibbles into bytes (even elements / odd elements), v_cvt_f32_ubyteN turns each byte into
 // an exact float u, and fma(u, s, -8 s) is the correctly rounded fp32 product (u - 8) * s that the CPU dequantiser
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   const int ntiles = N >> 4;
   const int nt0 = (blockIdx.x * 4 + wid) * NTW;          // this wavefront's first 16-column tile
 
+  STAMP_DECL;
   f32x4 acc[NTW][TM];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
@@ -251,6 +263,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
     __syncthreads();
     read_x(0, 2 * kg, xa);
     dequant(wr, sc, 0, wa);
+    STAMP(st_t1);
+    STAMP(st_a);
 
     // One K-block with both phases.  wc/sc_c: raw weights of tile t; wx/sc_x: those of tile t+1 (in flight since
     // the previous K-block).  After its last use wc is refilled with tile t+2, so two register sets alternate
@@ -266,9 +280,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       pin(wb);
       interleave(true, SPREAD_STAGING);
       if (!SPREAD_STAGING) store_x(buf ^ 1);
+      STAMP_ADD(st_sumA, st_a);
 #ifndef NV_ABL_NOBAR
       __syncthreads();
 #endif
+      STAMP_ADD(st_sumBar, st_a);
       // phase B: multiply (t, step 1); prepare (t+1, step 0)
       if (!SPREAD_STAGING) load_x(ahead);
       dequant(wx, sc_x, 0, wa);
@@ -278,6 +294,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       multiply(wb, xa, true, buf ^ 1, 2 * kg, false, 0);
       pin(wa);
       interleave(true, false);
+      STAMP_ADD(st_sumB, st_a);
     };
     // last K-block: nothing left to fetch
     auto last_kblock = [&](uint32_t (&wc)[NTW][WREG], uint16_t (&sc_c)[NTW]) {
@@ -298,6 +315,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       last_kblock(wr, sc);
     }
   }
+  STAMP(st_t2);
   __syncthreads();
 
   // ---- join the two k-step groups' accumulators through LDS, half of the tiles per pass.  In the first pass
@@ -398,7 +416,11 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
           for (int e = 0; e < 2; ++e) {
             const float gt = bits_to_f32<T>(f32_to_bits<T>(acc[j][i][e]));
             const float up = bits_to_f32<T>(f32_to_bits<T>(acc[j][i][2 + e]));
-            const float sl = bits_to_f32<T>(f32_to_bits<T>(gt / (1.0f + expf(-gt))));
+            // silu(g) = g / (1 + e^-g) through the hardware exp2 and reciprocal (about 1 ulp of fp32 each, far below
+            // the 16-bit rounding that follows); libm expf plus an IEEE division cost ~35 instructions per element
+            // and made this epilogue a tenth of the launch
+            const float sl = bits_to_f32<T>(f32_to_bits<T>(
+                gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt))));
             r[e] = sl * up;
           }
           *reinterpret_cast<uint32_t*>(out + m * out_stride + j0) = pack2<T>(r[0], r[1]);
@@ -413,6 +435,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       }
     }
   }
+#ifdef NV_STAMP
+  if (EPI != 2 && partial && lane == 0) {
+    uint64_t* st = reinterpret_cast<uint64_t*>(partial) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    st[0] = st_t1 - st_t0; st[1] = st_sumA; st[2] = st_sumBar; st[3] = st_sumB; st[4] = st_t2 - st_t1;
+    st[5] = __builtin_amdgcn_s_memtime() - st_t2; st[6] = st_t0; st[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // Sum the split-K slabs in slab order, add the bias, round to the model dtype.
