@@ -42,6 +42,13 @@ WORKLOADS = {
     "qwen2-7b-w4a16-b512-s1024": ("qwen2-7b", "w4a16", "bf16", 512, 1024),
     "qwen2-0.5b-fp16-b1-s128": ("qwen2-0.5b", None, "fp16", 1, 128),
 }
+# The reference's own benchmark script (bench.py:17-42 of nanovllm): 128 requests, prompt and output lengths drawn
+# from U[100, 128], temperature 0.6, ignore_eos, through LLM.generate (prefill and decode mixed by the scheduler).
+# name: (model, quantization, dtype)
+GENERATE_WORKLOADS = {
+    "ref-bench": ("qwen3-0.6b", None, "bf16"),                 # the reference's model (Qwen3-0.6B, bf16)
+    "ref-bench-qwen2-0.5b-w4a16": ("qwen2-0.5b", "w4a16", "bf16"),
+}
 DEFAULT_WORKLOAD = "qwen2-0.5b-w4a16-b128-s1024"
 DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
 
@@ -176,12 +183,88 @@ def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0)
                       f"eager PyTorch CPU oracle (setup {setup:.0f}s not timed)"}
 
 
+def time_prefill_attention(hf, lens, reps=20):
+    """One causal varlen prefill-attention launch on packed sequences of the given lengths, HIP-event timed inside a
+    hipGraph -> (seconds per launch, causal flops per launch = sum_i 2 * len_i^2 * H * D, QK^T and PV halves)."""
+    from byox_vllm_amd import kernels
+    H, Hkv, D = hf.num_attention_heads, hf.num_key_value_heads, hf.head_dim
+    T = sum(lens)
+    q = torch.randn(T, H, D, device="cuda", dtype=hf.dtype)
+    k = torch.randn(T, Hkv, D, device="cuda", dtype=hf.dtype)
+    v = torch.randn(T, Hkv, D, device="cuda", dtype=hf.dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    out = torch.empty_like(q)
+    call = lambda: kernels.attn_prefill(q, k, v, cu, cu, max(lens), D ** -0.5, out=out)  # noqa: E731
+    call()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            call()
+    graph.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    graph.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps, float(sum(2 * n * n * H * D for n in lens))
+
+
+def run_generate_workload(args):
+    """`--workload ref-bench*`: whole requests through LLM.generate, as the reference's bench.py times them.
+    `value` = requested output tokens / wall seconds of generate() (prefill included), mean over --steps runs."""
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.config import qwen2_config
+    assert args.gpus == 1, "the generate workloads run on one GPU"
+    model_name, quantization, dtype_name = GENERATE_WORKLOADS[args.workload]
+    hf = qwen2_config(model_name, dtype=DTYPES[dtype_name])
+    random.seed(0)
+    num_seqs, lo, hi = 128, 100, 128
+    prompts = [[random.randint(0, 10000) for _ in range(random.randint(lo, hi))] for _ in range(num_seqs)]
+    params = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=random.randint(lo, hi)) for _ in range(num_seqs)]
+    llm = LLM("synthetic", hf_config=hf, quantization=quantization, enforce_eager=args.eager, max_model_len=256,
+              max_num_seqs=num_seqs, max_num_batched_tokens=16384, kvcache_block_size=256, num_kvcache_blocks=2 * num_seqs + 8)
+    llm.generate([[1, 2, 3]], SamplingParams(max_tokens=4), use_tqdm=False)          # the reference's warm-up request
+    runs = []
+    for i in range(args.warmup + args.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        llm.generate(prompts, params, use_tqdm=False)
+        torch.cuda.synchronize()
+        if i >= args.warmup:
+            runs.append((time.perf_counter() - t0, dict(llm.last_stats)))
+    llm._exit()
+    out_tokens = sum(sp.max_tokens for sp in params)
+    wall = sum(r[0] for r in runs) / len(runs)
+    agg = {k: sum(r[1][k] for r in runs) for k in runs[0][1]}
+    kern_s, flops = time_prefill_attention(hf, [len(p) for p in prompts])
+    achieved = flops / kern_s / 1e12
+    line = {
+        "metric": "generate output tokens/s (prefill + decode, LLM.generate)", "value": round(out_tokens / wall, 1),
+        "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype_name, "data": "synthetic (random weights, random prompts)",
+        "config": {"workload": args.workload, "geometry": model_name, "weight_format": quantization or dtype_name,
+                   "requests": num_seqs, "prompt_len": f"U[{lo},{hi}]", "output_len": f"U[{lo},{hi}]", "temperature": 0.6,
+                   "step": "one LLM.generate over all requests (reference bench.py:17-42)", "graph": not args.eager},
+        "prefill_tok_s": round(agg["prefill_tokens"] / agg["prefill_s"], 1),
+        "decode_tok_s": round(agg["decode_tokens"] / agg["decode_s"], 1),
+        "prefill_steps": agg["prefill_steps"] // len(runs), "decode_steps": agg["decode_steps"] // len(runs),
+        "roofline": {"bound": "mfma", "kernel": "prefill_lds_kernel (causal varlen attention of the prefill step)",
+                     "achieved": round(achieved, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(achieved / 2500.0, 4), "traffic": None, "flops_per_launch": flops,
+                     "avg_launch_us": round(kern_s * 1e6, 2)},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + sorted(GENERATE_WORKLOADS))
     ap.add_argument("--parallelism", default=None, choices=["dp", "tp"],
                     help="N > 1: tp (default) = one model sharded over the ranks; dp = one replica per rank")
     ap.add_argument("--no-replicas", action="store_true", help="tp: skip the extra replicas_tok_s leg")
@@ -190,6 +273,10 @@ def main():
     ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
     args = ap.parse_args()
 
+    if args.workload in GENERATE_WORKLOADS:
+        args.steps, args.warmup = min(args.steps, 5), min(args.warmup, 1)
+        torch.cuda.set_device(0)
+        return run_generate_workload(args)
     if os.environ.get("NV_BENCH_FAULT_TIMEOUT"):   # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["NV_BENCH_FAULT_TIMEOUT"]), exit=True)

@@ -82,14 +82,23 @@ class LLMEngine:
             self._add_request(prompt, sp)
         results = {}
         prefill_tps = decode_tps = 0.0
+        # totals of this call, kept for callers that report prefill and decode throughput separately
+        stats = self.last_stats = {"prefill_tokens": 0, "prefill_s": 0.0, "prefill_steps": 0,
+                                   "decode_tokens": 0, "decode_s": 0.0, "decode_steps": 0}
         while not self._is_finished():
             t0 = perf_counter()
             finished, num_tokens = self._step()
             dt = perf_counter() - t0
             if num_tokens > 0:
                 prefill_tps = num_tokens / dt
+                stats["prefill_tokens"] += num_tokens
+                stats["prefill_s"] += dt
+                stats["prefill_steps"] += 1
             elif num_tokens < 0:
                 decode_tps = -num_tokens / dt
+                stats["decode_tokens"] -= num_tokens
+                stats["decode_s"] += dt
+                stats["decode_steps"] += 1
             if pbar is not None:
                 pbar.set_postfix({"Prefill": f"{int(prefill_tps)}tok/s", "Decode": f"{int(decode_tps)}tok/s"})
             for seq_id, token_ids in finished:
