@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--parallelism", default=None, choices=["dp", "tp"],
                     help="N > 1: tp (default) = one model sharded over the ranks; dp = one replica per rank")
     ap.add_argument("--no-replicas", action="store_true", help="tp: skip the extra replicas_tok_s leg")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "xgmi"],
+                    help="tp: torch.distributed all-reduce (RCCL) or the library's all-reduce fused with add-RMSNorm")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
@@ -317,7 +319,8 @@ def main():
                         kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
                         max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
                         max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
-                        enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0)
+                        enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0,
+                        xgmi_allreduce=tp_size > 1 and args.allreduce == "xgmi")
         r = ModelRunner(config, rank if tp_size > 1 else 0, None)
         r.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
         seqs_, next_block = make_sequences(batch, context, block_size)
@@ -378,6 +381,8 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
             "graph_captured": not runner.enforce_eager,
+            "allreduce": (("nv_allreduce_add_rmsnorm (peer-mapped memory)" if runner.comm is not None else
+                           "torch.distributed all_reduce") if tp > 1 else None),
             "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": bytes_step,
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ decode_combine_kernel)",

@@ -40,6 +40,17 @@ _PROTOS = {
     "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),
     "nv_gemm_rope_kv_store_is_faster": (_i, [_i64, _i, _i, _i, _i, _i]),
     "nv_gemm_rope_kv_store": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _p]),
+    "nv_comm_buffer_bytes": (_sz, [_i, _i, _i]),
+    "nv_comm_init": (_i, [C.POINTER(C.c_void_p), _i, _i, _i, _i]),
+    "nv_comm_memory_kind": (_i, [_p]),
+    "nv_comm_local_base": (_p, [_p]),
+    "nv_comm_export": (_i, [_p, _p]),
+    "nv_comm_open_peer": (_i, [_p, _i, _p]),
+    "nv_comm_set_peer": (_i, [_p, _i, _p]),
+    "nv_comm_error": (_i, [_p]),
+    "nv_comm_destroy": (_i, [_p]),
+    "nv_allreduce": (_i, [_p, _p, _p, _i, _p, _i64, _i, _i, _p]),
+    "nv_allreduce_add_rmsnorm": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
     "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
     "nv_sample_workspace_bytes": (_sz, [_i]),
     "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _p, _i, _p]),

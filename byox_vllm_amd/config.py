@@ -8,6 +8,8 @@ Differences from the reference, all supersets:
   because of flash-attn; the HIP kernels take the block size at run time).
 * ``state_dict`` supplies an in-memory checkpoint (packed parameter names) instead
   of safetensors files; with neither, synthetic weights are drawn from ``seed``.
+* ``xgmi_allreduce`` (or NV_XGMI_ALLREDUCE=1) routes the tensor-parallel all-reduces through
+  ``nv_allreduce_add_rmsnorm`` (peer-mapped device memory) instead of torch.distributed.
 * ``quantization`` selects the weight format of the layer linears:
   ``None`` (dense), ``"w8a16"`` or ``"w4a16"``.
 """
@@ -56,6 +58,7 @@ class Config:
     num_kvcache_blocks: int = -1
     quantization: str | None = None
     seed: int = 0
+    xgmi_allreduce: bool = False    # tensor parallel: the library's own all-reduce fused with add-RMSNorm instead of RCCL
     graph_head: bool = True         # single rank: LM head + sampler inside the decode graph (False: forward only)
     graph_batch_sizes: Any = None   # optional list: capture decode graphs only for these padded batch sizes
     state_dict: Any = None   # optional in-memory checkpoint keyed by the packed parameter names

@@ -40,8 +40,13 @@ class ModelRunner:
         self.config = config
         hf_config = config.hf_config
         self.block_size = config.kvcache_block_size
+        self.use_xgmi = config.tensor_parallel_size > 1 and (
+            config.xgmi_allreduce or os.environ.get("NV_XGMI_ALLREDUCE", "0") == "1")
+        # gloo collectives cannot be captured; with the library's own all-reduce nothing of torch.distributed is
+        # left inside the forward pass, so the graph path works under any host-side backend
         self.enforce_eager = config.enforce_eager or (
-            config.tensor_parallel_size > 1 and os.environ.get("NV_DIST_BACKEND", "nccl") != "nccl")
+            config.tensor_parallel_size > 1 and os.environ.get("NV_DIST_BACKEND", "nccl") != "nccl"
+            and not self.use_xgmi)
         self.world_size = config.tensor_parallel_size
         self.rank = rank
         self.event = event
@@ -55,8 +60,10 @@ class ModelRunner:
             dist.init_process_group(os.environ.get("NV_DIST_BACKEND", "nccl"), "tcp://127.0.0.1:2333",
                                     world_size=self.world_size, rank=rank)
             self._own_pg = True
-        from byox_vllm_amd.layers.linear import set_tp
+        from byox_vllm_amd.layers.linear import set_comm, set_tp
         set_tp(rank if self.world_size > 1 else 0, self.world_size, getattr(config, "tp_group", None))
+        set_comm(None)
+        self.comm = None
         local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         self.device = torch.device("cuda", local)
@@ -64,6 +71,12 @@ class ModelRunner:
         torch.set_default_dtype(hf_config.dtype)
         torch.set_default_device(self.device)
         try:
+            if self.use_xgmi:
+                from byox_vllm_amd.layers.comm import XgmiComm
+                self.comm = XgmiComm(rank, self.world_size, config.max_num_batched_tokens, hf_config.hidden_size)
+                self.comm.connect(getattr(config, "tp_group", None))
+                set_comm(self.comm)
+                logger.info("tensor-parallel all-reduce over peer-mapped %s device memory", self.comm.memory_kind)
             self.model = Qwen3ForCausalLM(hf_config)
             self._load_weights()
             self.model.finalize(config.quantization)
@@ -148,6 +161,13 @@ class ModelRunner:
         if not self.enforce_eager:
             self.graphs, self.graph_pool = {}, None
         torch.cuda.synchronize()
+        if self.comm is not None:
+            from byox_vllm_amd.layers.linear import set_comm
+            if self.world_size > 1 and dist.is_initialized():
+                dist.barrier()        # no peer may still be reading this rank's buffer
+            set_comm(None)
+            self.comm.close()
+            self.comm = None
         if self._own_pg:
             dist.destroy_process_group()
 

@@ -38,6 +38,15 @@ class Partials:
         self.slabs, self.n, self.rows, self.cols, self.bias, self.dtype = slabs, n, rows, cols, bias, dtype
 
 
+class PendingReduce:
+    """Output of a row-parallel linear that still has to be summed over the tensor-parallel ranks: ``value`` is this
+    rank's contribution (a tensor or the Partials of its split-K GEMM).  Consumed by RMSNorm, which runs the
+    all-reduce fused with its residual add and normalisation (layers/comm.py)."""
+
+    def __init__(self, value):
+        self.value = value
+
+
 def rms_norm(x, weight, eps, out=None):
     require_gpu(x, "rms_norm")
     hidden = x.size(-1)

@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from byox_vllm_amd import kernels
-from byox_vllm_amd.layers.linear import _tp, tp_all_reduce, tp_gather
+from byox_vllm_amd.layers.linear import _tp, get_comm, tp_all_reduce, tp_gather
 from byox_vllm_amd.layers.quant import LinearWeight
 from byox_vllm_amd.utils.context import get_context
 
@@ -29,6 +29,8 @@ class VocabParallelEmbedding(nn.Module):
         # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
         y = kernels.embed(x, self.weight.data, self.vocab_start_idx)
         if self.tp_size > 1:
+            if get_comm() is not None:
+                return get_comm().all_reduce(y)
             tp_all_reduce(y)
         return y
 

@@ -17,6 +17,9 @@ class RMSNorm(nn.Module):
 
     def add_rms_forward(self, x, residual: torch.Tensor):
         # x may be a kernels.Partials (split-K slabs of the preceding linear).  The residual is updated in place.
+        if isinstance(x, kernels.PendingReduce):   # tensor parallel: all-reduce + add + norm in one launch; the
+            from byox_vllm_amd.layers.linear import get_comm   # residual stays sharded by rows (layers/comm.py)
+            return get_comm().all_reduce_add_rms_norm(x.value, residual, self.weight.data, self.eps)
         if isinstance(x, kernels.Partials):
             return kernels.add_rms_norm(x, residual, self.weight.data, self.eps, residual_out=residual)
         return kernels.add_rms_norm(x, residual, self.weight.data, self.eps, out=x, residual_out=residual)

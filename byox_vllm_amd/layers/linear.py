@@ -101,6 +101,18 @@ def set_tp(rank: int, size: int, group=None) -> None:
     _TP_STATE = (rank, size, group)
 
 
+_COMM = None   # layers.comm.XgmiComm of this rank, or None: collectives then go through torch.distributed (RCCL)
+
+
+def set_comm(comm) -> None:
+    global _COMM
+    _COMM = comm
+
+
+def get_comm():
+    return _COMM
+
+
 def tp_group():
     return _TP_STATE[2] if _TP_STATE is not None else None
 
@@ -283,6 +295,9 @@ class RowParallelLinear(LinearBase):
         bias = self.bias.data if (self.bias is not None and self.tp_rank == 0) else None
         if partial_out and self.tp_size == 1 and bias is None:
             return self._gemm(x, None, partial_out=True)
+        if partial_out and self.tp_size > 1 and _COMM is not None:
+            # the sum over ranks is taken by the consumer: the all-reduce fused with the following add-RMSNorm
+            return kernels.PendingReduce(self._gemm(x, None, partial_out=True) if bias is None else self._gemm(x, bias))
         y = self._gemm(x, bias, out=out)
         if self.tp_size > 1:
             tp_all_reduce(y)

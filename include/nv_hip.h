@@ -224,6 +224,41 @@ int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_
                            int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,
                            uint64_t* step_counter, nv_stream_t stream);
 
+/* ---- all-reduce over peer-mapped device memory (xGMI), fused with the residual add and RMSNorm that follow it.
+ * Replaces dist.all_reduce after RowParallelLinear (nanovllm/layers/linear.py:145-146) and after the vocab-parallel
+ * embedding (layers/embed_head.py:38-40) together with the add_rms_forward that consumes the sum
+ * (layers/layernorm.py:28-40), and NCCL's process-group set-up for them (engine/model_runner.py:27).
+ *
+ * nv_comm_init allocates this rank's buffer (nv_comm_buffer_bytes; uncached device memory) and is the only call
+ * that allocates.  The caller then exchanges the 64-byte handles of nv_comm_export between the ranks (any host
+ * channel: torch.distributed, a pipe) and maps every peer with nv_comm_open_peer (another process: hipIpc) or
+ * nv_comm_set_peer (same process).  Every rank must issue the same sequence of nv_allreduce* calls (SPMD, as the
+ * reference's ranks do); the calls keep their call counter in device memory, take no per-call host argument and can
+ * be captured into a hipGraph.  A rank owns rows [r*R, (r+1)*R), R = ceil(rows / world):
+ *   nv_allreduce             out[rows, hidden] = to_dtype(sum over ranks of x), the same bits on every rank (fp32 sum
+ *                            in rank order, one rounding);
+ *   nv_allreduce_add_rmsnorm out = RMSNorm(to_dtype(sum) + residual) * weight for ALL rows; residual_out only for
+ *                            the rows this rank owns: the residual stream stays sharded by rows, each rank reads and
+ *                            writes only its own rows of residual / residual_out (they may be the same buffer).
+ * x may be NULL when `partials` (num_partials fp32 slabs [rows, hidden] of a split-K nv_gemm) is given: the rank's
+ * contribution is then to_dtype(sum of the slabs).  nv_comm_error returns non-zero after a wait for a peer ran out
+ * (about two seconds); it reads device memory and synchronises. */
+typedef struct nv_comm nv_comm_t;
+size_t nv_comm_buffer_bytes(int world, int max_rows, int hidden);
+int nv_comm_init(nv_comm_t** comm, int rank, int world, int max_rows, int hidden);
+int nv_comm_memory_kind(const nv_comm_t* comm);   /* 2 uncached, 1 fine-grained, 0 plain device memory */
+void* nv_comm_local_base(const nv_comm_t* comm);
+int nv_comm_export(nv_comm_t* comm, void* handle64);
+int nv_comm_open_peer(nv_comm_t* comm, int peer, const void* handle64);
+int nv_comm_set_peer(nv_comm_t* comm, int peer, void* base);
+int nv_comm_error(nv_comm_t* comm);
+int nv_comm_destroy(nv_comm_t* comm);
+int nv_allreduce(nv_comm_t* comm, const void* x, const float* partials, int num_partials, void* out, int64_t rows,
+                 int hidden, int dtype, nv_stream_t stream);
+int nv_allreduce_add_rmsnorm(nv_comm_t* comm, const void* x, const float* partials, int num_partials,
+                             const void* residual, const void* weight, void* out, void* residual_out, int64_t rows,
+                             int hidden, float eps, int dtype, nv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

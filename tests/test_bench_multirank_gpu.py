@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["dp", "default"])
+@pytest.mark.parametrize("mode", ["dp", "default", "xgmi"])
 def test_bench_two_ranks(mode):
     """`default` passes no --parallelism, as the round driver does: with more than one rank that is the tensor-parallel
     split (one model over both ranks, all-reduce on the data path) plus the replicas leg."""
@@ -20,7 +20,8 @@ def test_bench_two_ranks(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29533" if mode == "dp" else "29534",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--workload", "qwen2-0.5b-fp16-b1-s128"] + (["--parallelism", "dp"] if mode == "dp" else [])
+           "--workload", "qwen2-0.5b-fp16-b1-s128"] + (["--parallelism", "dp"] if mode == "dp" else []) + (
+               ["--allreduce", "xgmi"] if mode == "xgmi" else [])
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -30,5 +31,6 @@ def test_bench_two_ranks(mode):
     assert d["scaling"] == ("weak" if mode == "dp" else "strong")
     assert d["config"]["parallelism"] == ("dp2" if mode == "dp" else "tp2")
     assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert d["graph_captured"] == (mode != "default")      # gloo collectives cannot be captured, the library's own can
     assert ("replicas_tok_s" in d) == (mode != "dp") and d.get("replicas_tok_s", 1) > 0
     assert "cpu_baseline" not in d                      # rank 0 times the CPU baseline at N = 1 only

@@ -218,11 +218,15 @@ def test_engine_preemption_matches_oracle(golden, eager):
 
 
 @pytest.mark.parametrize("tp", [2, 4])
-def test_engine_tensor_parallel_matches_oracle(golden, tp, monkeypatch):
+@pytest.mark.parametrize("collectives", ["gloo", "xgmi-eager", "xgmi-graph"])
+def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypatch):
     """The whole tensor-parallel runtime on one GPU: worker spawn, shared-memory control messages, sharded weights
     (tp=2: the reference's split; tp=4 on 4/2 heads: KV-head replication, a zero-padded query slot per rank, two
     ranks with an all-zero MLP shard), all-reduce and logits gather.  The ranks share the device, so the process
-    group is gloo with a host hop (NV_DIST_BACKEND) and the steps run eagerly; RCCL needs one GPU per rank."""
+    group is gloo (NV_DIST_BACKEND; RCCL needs one GPU per rank).  `gloo`: the all-reduces take a host hop and the
+    steps run eagerly.  `xgmi-*`: the all-reduces run through nv_allreduce_add_rmsnorm / nv_allreduce on buffers the
+    ranks map into each other by hipIpc handles, eagerly and inside every rank's captured decode graph (the path a
+    multi-GPU node replays: staging kernel -> graph with in-graph collectives -> LM head and gather outside)."""
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
@@ -233,8 +237,8 @@ def test_engine_tensor_parallel_matches_oracle(golden, tp, monkeypatch):
     prompts = [rng.randint(0, 256, size=n).tolist() for n in (7, 21, 16)]
     want, margin = _oracle_generate(cfg, weights, prompts, max_tokens=8, num_blocks=16)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=16,
-              enforce_eager=True, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
-              tensor_parallel_size=tp)
+              enforce_eager=collectives != "xgmi-graph", max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
+              tensor_parallel_size=tp, xgmi_allreduce=collectives != "gloo")
     try:
         outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True), use_tqdm=False)
     finally:
