@@ -70,6 +70,8 @@ class Config:
         if self.hf_config is None:
             assert os.path.isdir(self.model)
             self.hf_config = _load_hf_config(self.model)
+            if self.quantization is None:       # a checkpoint written by utils/quantize.py names its format
+                self.quantization = getattr(self.hf_config, "quantization", None)
         if getattr(self.hf_config, "dtype", None) is None:
             self.hf_config.dtype = torch.bfloat16
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)

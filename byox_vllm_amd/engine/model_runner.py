@@ -113,7 +113,7 @@ class ModelRunner:
         else:
             if not (isinstance(path, str) and os.path.isdir(path) and glob.glob(os.path.join(path, "*.safetensors"))):
                 raise FileNotFoundError(f"no *.safetensors under {path!r} (pass model='synthetic' for random weights)")
-            load_model(self.model, path)
+            load_model(self.model, path, self.config.quantization)
 
     # ------------------------------------------------------------------ RPC (tensor parallel)
     def call(self, method_name, *args):

@@ -173,17 +173,60 @@ class LinearBase(nn.Module):
 
     def finalize(self, quantization: str | None = None) -> None:
         """Build the kernel-side weight; quantised layers free the dense parameter."""
-        self.packed = LinearWeight.make(self.weight.data, quantization)
+        self.packed = self._pack(lambda t: t, quantization)
         if quantization is not None:
             self.weight = None
 
-    def _gemm(self, x, bias, out=None, **kw):
-        if self.packed is None:
-            self.finalize(None)
-        return kernels.gemm(x, self.packed, bias, out=out, **kw)
+    def _pack(self, reorder, quantization):
+        """The kernel-side weight of this rank's shard: quantised here from the dense parameter, or taken as it was
+        quantised offline (load_quantized); ``reorder`` permutes rows (gate/up interleaving)."""
+        self._finish_quantized()
+        q = getattr(self, "_quantized", None)
+        if q is not None:
+            assert quantization == q[2], f"checkpoint holds {q[2]} weights, the engine was asked for {quantization}"
+            self._quantized = None
+            return LinearWeight.from_quantized(reorder(q[0]), reorder(q[1]), q[2])
+        return LinearWeight.make(reorder(self.weight.data), quantization)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError
+    def load_quantized(self, values: torch.Tensor, scales: torch.Tensor, quantization: str, *shard_id) -> None:
+        """Shard an offline-quantised matrix (values int8 [N, K], scales [N, K/128], both of the FULL layer) exactly as
+        weight_loader shards the dense one: the loaders only move rows and 128-aligned column blocks around, so they
+        are run once on the values and once on the scales spread to one per element; rows and columns the rank pads
+        with zeros get the zero weight and the scale a zero group quantises to."""
+        q = getattr(self, "_quantized", None)
+        if q is None:
+            shape = self.weight.shape
+            q = self._quantized = (torch.zeros(shape, dtype=torch.int8, device=values.device),
+                                   torch.zeros(shape, dtype=scales.dtype, device=values.device), quantization)
+        self.weight_loader(q[0], values, *shard_id)
+        self.weight_loader(q[1], scales.repeat_interleave(128, dim=1), *shard_id)
+
+    def _finish_quantized(self) -> None:
+        """One scale per element -> one per local group of 128.  A local group normally lies inside one group of the
+        full matrix (plus zero padding) and keeps that group's scale and values.  Where the shard boundaries are not
+        128-aligned in the full matrix (64-wide heads dealt unevenly) a local group can straddle two full groups with
+        different scales: such groups are re-quantised from their dequantised values, as load-time quantisation of the
+        dense shard would do."""
+        q = getattr(self, "_quantized", None)
+        if q is None or q[1].size(1) != q[0].size(1):
+            return
+        values, per_elem, quantization = q
+        n, k = values.shape
+        g = per_elem.float().view(n, k // 128, 128)
+        top = g.amax(-1)
+        low = torch.where(g == 0, torch.full_like(g, float("inf")), g).amin(-1)
+        mixed = (top != low) & (top != 0)
+        scales = top.to(per_elem.dtype)
+        scales[top == 0] = torch.tensor(1e-8, dtype=torch.float32).to(per_elem.dtype)   # an all-zero group's scale
+        if mixed.any():
+            qmax = 7 if quantization == "w4a16" else 127
+            w = (values.float().view(n, k // 128, 128) * g)[mixed]
+            s_new = (w.abs().amax(-1) / qmax).clamp_min(1e-8).to(per_elem.dtype)
+            v_new = torch.clamp(torch.round(w / s_new.float().unsqueeze(-1)), -8 if qmax == 7 else -127, qmax)
+            values = values.clone()
+            values.view(n, k // 128, 128)[mixed] = v_new.to(torch.int8)
+            scales[mixed] = s_new
+        self._quantized = (values, scales, quantization)
 
 
 class ReplicatedLinear(LinearBase):
@@ -231,8 +274,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         """fuse_silu: store gate/up rows interleaved so forward_silu_mul() can apply SiluAndMul in the GEMM epilogue."""
         from byox_vllm_amd.layers.quant import interleave_gate_up
         self.fused_silu = fuse_silu and self.bias is None and len(self.output_sizes) == 2
-        w = interleave_gate_up(self.weight.data) if self.fused_silu else self.weight.data
-        self.packed = LinearWeight.make(w, quantization)
+        self.packed = self._pack(interleave_gate_up if self.fused_silu else (lambda t: t), quantization)
         if quantization is not None or self.fused_silu:
             self.weight = None
 

@@ -94,20 +94,42 @@ class LinearWeight:
     def int4(cls, w: torch.Tensor):
         n, k = w.shape
         g, s = _scales(w, 7)
-        u = (torch.clamp(torch.round(g / s.float().unsqueeze(-1)), -8, 7) + 8).to(torch.int32).view(n, k)
-        shifts = torch.arange(0, 32, 4, device=w.device, dtype=torch.int32)
-        tiled = (_tile_index_view(u) << shifts).sum(dim=-1, dtype=torch.int64)
-        tiled = (tiled & 0xFFFFFFFF).to(torch.int64)
-        tiled = torch.where(tiled >= 2 ** 31, tiled - 2 ** 32, tiled).to(torch.int32)
-        return cls(W_INT4, tiled.reshape(n // 16, k // GROUP, 64, 4).contiguous(), s.t().contiguous(), n, k, w.dtype)
+        v = torch.clamp(torch.round(g / s.float().unsqueeze(-1)), -8, 7).to(torch.int8).view(n, k)
+        return cls.from_quantized(v, s, "w4a16")
 
     @classmethod
     def int8(cls, w: torch.Tensor):
         n, k = w.shape
         g, s = _scales(w, 127)
         q = torch.clamp(torch.round(g / s.float().unsqueeze(-1)), -127, 127).to(torch.int8).view(n, k)
-        tiled = _tile_index_view(q).reshape(n // 16, k // GROUP, 64, 32).contiguous()
-        return cls(W_INT8, tiled, s.t().contiguous(), n, k, w.dtype)
+        return cls.from_quantized(q, s, "w8a16")
+
+    @classmethod
+    def from_quantized(cls, values: torch.Tensor, scales: torch.Tensor, quantization: str):
+        """Kernel-side weight from already quantised values: ``values`` int8 [N, K] (int4: -8..7, int8: -127..127),
+        ``scales`` [N, K/128] in the model dtype.  What int4()/int8() end in, and what a checkpoint quantised offline
+        (utils/quantize.py) is loaded through, so both give the same bytes."""
+        n, k = values.shape
+        assert values.dtype == torch.int8 and scales.shape == (n, k // GROUP) and k % GROUP == 0 and n % 16 == 0
+        if quantization == "w8a16":
+            tiled = _tile_index_view(values).reshape(n // 16, k // GROUP, 64, 32).contiguous()
+            return cls(W_INT8, tiled, scales.t().contiguous(), n, k, scales.dtype)
+        assert quantization == "w4a16"
+        u = values.to(torch.int32) + 8
+        shifts = torch.arange(0, 32, 4, device=values.device, dtype=torch.int32)
+        tiled = (_tile_index_view(u) << shifts).sum(dim=-1, dtype=torch.int64)
+        tiled = (tiled & 0xFFFFFFFF).to(torch.int64)
+        tiled = torch.where(tiled >= 2 ** 31, tiled - 2 ** 32, tiled).to(torch.int32)
+        return cls(W_INT4, tiled.reshape(n // 16, k // GROUP, 64, 4).contiguous(), scales.t().contiguous(), n, k, scales.dtype)
+
+    def quantized_values(self):
+        """-> (int8 [N, K] values, scales [N, K/128]): the inverse of from_quantized."""
+        if self.fmt == W_INT8:
+            return self.logical_int8()
+        packed, scales = self.logical_int4()
+        n = packed.size(0)
+        u = torch.stack((packed & 0xF, packed >> 4), dim=-1).view(n, -1)
+        return (u.to(torch.int16) - 8).to(torch.int8), scales
 
     @classmethod
     def make(cls, w: torch.Tensor, quantization: str | None):

@@ -18,6 +18,23 @@ def default_weight_loader(param: nn.Parameter, loaded_weight: torch.Tensor):
     param.data.copy_(loaded_weight)
 
 
+def _load_quantized(model, packed, pending, name, tensor, quantization):
+    """A ``.qweight`` / ``.scales`` pair of an offline-quantised checkpoint (utils/quantize.py): once both halves of a
+    matrix have been read they go to the owning layer's load_quantized, which shards them like a dense weight."""
+    base, kind = name.rsplit(".", 1)
+    pair = pending.setdefault(base, {})
+    pair[kind] = tensor
+    if len(pair) < 2:
+        return
+    del pending[base]
+    for hf_key, (packed_key, shard_id) in packed.items():
+        if hf_key in base:
+            model.get_submodule(base.replace(hf_key, packed_key)).load_quantized(pair["qweight"], pair["scales"],
+                                                                                 quantization, shard_id)
+            return
+    model.get_submodule(base).load_quantized(pair["qweight"], pair["scales"], quantization)
+
+
 def _load_one(model, packed, name, tensor):
     for hf_key, (packed_key, shard_id) in packed.items():
         if hf_key in name:
@@ -28,13 +45,19 @@ def _load_one(model, packed, name, tensor):
     getattr(param, "weight_loader", default_weight_loader)(param, tensor)
 
 
-def load_model(model: nn.Module, path: str):
+def load_model(model: nn.Module, path: str, quantization: str | None = None):
     from safetensors import safe_open
     packed = getattr(model, "packed_modules_mapping", {})
+    pending: dict = {}
     for file in sorted(glob(os.path.join(path, "*.safetensors"))):
         with safe_open(file, "pt", "cpu") as f:
             for name in f.keys():  # noqa: SIM118
-                _load_one(model, packed, name, f.get_tensor(name))
+                if name.endswith((".qweight", ".scales")):
+                    assert quantization is not None, f"{name}: quantised checkpoint, but no quantisation was configured"
+                    _load_quantized(model, packed, pending, name, f.get_tensor(name), quantization)
+                else:
+                    _load_one(model, packed, name, f.get_tensor(name))
+    assert not pending, f"qweight/scales without their other half: {sorted(pending)}"
 
 
 def load_state_dict_packed(model: nn.Module, weights: dict, cfg) -> None:

@@ -93,3 +93,97 @@ def test_missing_checkpoint_is_an_error_not_random_weights(tmp_path):
     runner.model = None
     with pytest.raises(FileNotFoundError):
         runner._load_weights()
+
+
+@pytest.mark.parametrize("quant", ["w4a16", "w8a16"])
+@pytest.mark.parametrize("style,tp", [("qwen2", (0, 1)), ("qwen2", (1, 2)), ("qwen3", (0, 2)), ("qwen3", (1, 2)),
+                                      ("qwen2", (0, 4)), ("qwen2", (3, 4))])   # 4 ranks: zero-padded heads, empty MLP shards
+def test_offline_quantised_checkpoint_gives_the_same_bytes(tmp_path, quant, style, tp):
+    """utils.quantize writes the quantised checkpoint once; loading it (any rank, incl. the replicated-KV-head and
+    zero-padded layouts of qwen3-style on 2 ranks) must give the packed weights and scales that quantising the rank's
+    dense shard at load time gives, bit for bit, and the fused gate/up row order."""
+    from safetensors.torch import save_file
+
+    from byox_vllm_amd.layers.linear import LinearBase
+    from byox_vllm_amd.utils.loader import load_model
+    from byox_vllm_amd.utils.quantize import quantize_checkpoint
+    cfg = OM.tiny_config(style, torch.bfloat16)
+    named = hf_named(cfg, OM.random_weights(cfg, seed=4))
+    src, dst = tmp_path / "dense", tmp_path / "quant"
+    src.mkdir()
+    save_file(named, str(src / "model.safetensors"))
+    with open(src / "config.json", "w") as f:
+        json.dump({"hidden_size": cfg.hidden_size}, f)
+    quantize_checkpoint(str(src), str(dst), quant)
+    assert json.load(open(dst / "config.json"))["quantization"] == quant
+    from safetensors import safe_open
+    with safe_open(str(dst / "model.safetensors"), "pt", "cpu") as f:
+        names = set(f.keys())
+    assert "model.layers.0.self_attn.q_proj.qweight" in names and "model.layers.0.self_attn.q_proj.weight" not in names
+    assert "model.embed_tokens.weight" in names and "model.layers.0.mlp.down_proj.scales" in names
+
+    from oracle import quant as Q
+    a, b, c = build(cfg, *tp), build(cfg, *tp), build(cfg, *tp)
+    load_model(a, str(dst), quant)        # quantised offline
+    load_model(b, str(src))               # dense, quantised at load time
+    # c: the offline-quantised MODEL as dense weights (what every rank's shard must dequantise to)
+    dq = {}
+    for name, w in named.items():
+        is_q = name.endswith(("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weight", "gate_proj.weight",
+                              "up_proj.weight", "down_proj.weight"))
+        if is_q:
+            dq[name] = Q.dequantize_w4(*Q.quantize_w4(w)) if quant == "w4a16" else Q.dequantize_w8(*Q.quantize_w8(w))
+        else:
+            dq[name] = w
+    (tmp_path / "deq").mkdir()
+    save_file(dq, str(tmp_path / "deq" / "model.safetensors"))
+    load_model(c, str(tmp_path / "deq"))
+    dense_shards = {n: m.weight.data.clone() for n, m in c.named_modules() if isinstance(m, LinearBase)}
+    a.finalize(quant)
+    b.finalize(quant)
+    c.finalize(None)
+    from byox_vllm_amd.layers.quant import interleave_gate_up
+    checked = 0
+    aligned = tp[1] <= 2          # these tiny shapes: shards are whole 128-column groups of the full matrices
+    for (na, ma), (nb, mb) in zip(a.named_modules(), b.named_modules()):
+        if isinstance(ma, LinearBase):
+            assert ma.packed.fmt == mb.packed.fmt and na == nb
+            if aligned:   # then quantising offline and quantising the rank's dense shard are the same computation
+                assert torch.equal(ma.packed.data, mb.packed.data), na
+                assert torch.equal(ma.packed.scales, mb.packed.scales), na
+            # always: the rank's weights dequantise to its shard of the offline-quantised model (the oracle's dequantiser)
+            v, sc = ma.packed.quantized_values()
+            got = (v.float().view(v.size(0), -1, 128) * sc.float().unsqueeze(-1)).view(v.shape).to(torch.bfloat16)
+            want = dense_shards[na]
+            if na.endswith("gate_up_proj"):
+                want = interleave_gate_up(want)
+            assert torch.equal(got, want), na
+            checked += 1
+    assert checked == 4 * cfg.num_hidden_layers
+
+
+def test_offline_quantised_groups_that_straddle_a_shard_boundary_are_requantised():
+    """A shard whose columns start in the middle of a 128-column group of the full matrix (64-wide heads dealt
+    unevenly over the ranks): the local group mixes two scales and is re-quantised from the dequantised values,
+    i.e. it equals load-time quantisation of the dequantised dense shard."""
+    from byox_vllm_amd.layers.linear import RowParallelLinear, set_tp
+    from byox_vllm_amd.layers.quant import LinearWeight
+    from byox_vllm_amd.utils.quantize import quantize_tensor
+    set_tp(0, 1)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        layers = [RowParallelLinear(384, 32, input_segments=[(64, 128, 0)], local_input_size=128) for _ in range(2)]
+    finally:
+        torch.set_default_dtype(torch.float32)
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(32, 384, generator=g) * 0.05 * torch.tensor([1.0] * 128 + [4.0] * 256)).to(torch.bfloat16)
+    values, scales = quantize_tensor(w, "w4a16")
+    assert not torch.equal(scales[:, 0], scales[:, 1])
+    layers[0].load_quantized(values, scales, "w4a16")
+    layers[0].finalize("w4a16")
+    deq = (values.float().view(32, 3, 128) * scales.float().unsqueeze(-1)).view(32, 384).to(torch.bfloat16)
+    layers[1].weight_loader(layers[1].weight, deq)
+    layers[1].finalize("w4a16")
+    assert torch.equal(layers[0].packed.data, layers[1].packed.data)
+    assert torch.equal(layers[0].packed.scales, layers[1].packed.scales)
+    assert isinstance(layers[0].packed, LinearWeight)
