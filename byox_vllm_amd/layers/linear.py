@@ -220,7 +220,7 @@ class LinearBase(nn.Module):
         scales[top == 0] = torch.tensor(1e-8, dtype=torch.float32).to(per_elem.dtype)   # an all-zero group's scale
         if mixed.any():
             qmax = 7 if quantization == "w4a16" else 127
-            w = (values.float().view(n, k // 128, 128) * g)[mixed]
+            w = (values.float().view(n, k // 128, 128) * g)[mixed].to(per_elem.dtype).float()   # the dense weight's value
             s_new = (w.abs().amax(-1) / qmax).clamp_min(1e-8).to(per_elem.dtype)
             v_new = torch.clamp(torch.round(w / s_new.float().unsqueeze(-1)), -8 if qmax == 7 else -127, qmax)
             values = values.clone()
