@@ -228,6 +228,14 @@ class LinearBase(nn.Module):
             scales[mixed] = s_new
         self._quantized = (values, scales, quantization)
 
+    def _gemm(self, x, bias, out=None, **kw):
+        if self.packed is None:
+            self.finalize(None)
+        return kernels.gemm(x, self.packed, bias, out=out, **kw)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
 
 class ReplicatedLinear(LinearBase):
     def __init__(self, input_size: int, output_size: int, bias: bool = False):
