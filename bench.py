@@ -359,11 +359,12 @@ def main():
     # profiles/: counters cannot be read from inside this process, so the measured traffic/algorithmic ratio
     # of the same kernel and head geometry is applied to this run's byte count.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_attn_decode_hbm_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r02_attn_decode_hbm_traffic.json")
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        if pmc["shape"]["D"] == hf.head_dim and pmc["shape"]["Hkv"] == max(1, hf.num_key_value_heads // tp):
-            traffic = int(kv_bytes * pmc["traffic_over_algorithmic"])
+        for entry in [pmc] + pmc.get("others", []):
+            if entry["shape"]["D"] == hf.head_dim and entry["shape"]["Hkv"] == max(1, hf.num_key_value_heads // tp):
+                traffic = int(kv_bytes * entry["traffic_over_algorithmic"])
 
     if rank == 0:
         line = {

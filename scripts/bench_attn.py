@@ -60,6 +60,10 @@ if __name__ == "__main__":
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     if which == "0.5b":
         run(128, 14, 2, 64, S, 24, [1, 2, 4])
+    elif which == "pmc":      # one configuration only, for counter passes: every paged_decode launch is the same
+        run(128, 14, 2, 64, S, 24, [1])
+    elif which == "pmc7b":
+        run(128, 28, 4, 128, S, 8, [1])
     elif which == "7b":
         run(128, 28, 4, 128, S, 8, [1, 2])
     elif which == "prefill":
