@@ -53,7 +53,13 @@ class ModelRunner:
         if not torch.cuda.is_available():
             raise RuntimeError("ModelRunner needs an MI355X: byox_vllm_amd has no CPU compute path")
 
+        # NV_TP_SINGLE_RANK_RCCL=1: a one-GPU machine runs the tensor-parallel code path for real: RCCL process group
+        # of one rank, every collective issued (and captured into the decode graphs), LM head and sampler outside
+        self.single_rank_rccl = self.world_size == 1 and os.environ.get("NV_TP_SINGLE_RANK_RCCL", "0") == "1"
         self._own_pg = False
+        if self.single_rank_rccl and not dist.is_initialized():
+            dist.init_process_group("nccl", "tcp://127.0.0.1:2334", world_size=1, rank=0)
+            self._own_pg = True
         if self.world_size > 1 and not dist.is_initialized():
             # NV_DIST_BACKEND=gloo: rehearsal of the tensor-parallel runtime with the ranks sharing GPUs (RCCL wants one
             # device per rank); gloo collectives cannot be captured, so that mode runs eagerly
@@ -61,7 +67,8 @@ class ModelRunner:
                                     world_size=self.world_size, rank=rank)
             self._own_pg = True
         from byox_vllm_amd.layers.linear import set_comm, set_tp
-        set_tp(rank if self.world_size > 1 else 0, self.world_size, getattr(config, "tp_group", None))
+        set_tp(rank if self.world_size > 1 else 0, self.world_size, getattr(config, "tp_group", None),
+               single_rank_collectives=self.single_rank_rccl)
         set_comm(None)
         self.comm = None
         local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
@@ -406,7 +413,7 @@ class ModelRunner:
         # Single rank: the graph also stages its inputs and ends in LM head + sampler.  With tensor parallelism (or
         # Config.graph_head = False) it holds the forward only; logits gather and sampling follow outside, as in the
         # reference (model_runner.py:253-254).
-        self.graph_has_head = self.world_size == 1 and self.config.graph_head
+        self.graph_has_head = self.world_size == 1 and self.config.graph_head and not self.single_rank_rccl
         self.graph_bs = sorted(config.graph_batch_sizes) if config.graph_batch_sizes else graph_batch_sizes(max_bs)
         max_bs = self.graph_bs[-1]
         self.max_graph_bs = max_bs

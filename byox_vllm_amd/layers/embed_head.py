@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 from byox_vllm_amd import kernels
-from byox_vllm_amd.layers.linear import _tp, get_comm, tp_all_reduce, tp_gather
+from byox_vllm_amd.layers.linear import _tp, collectives_on, get_comm, tp_all_reduce, tp_gather
 from byox_vllm_amd.layers.quant import LinearWeight
 from byox_vllm_amd.utils.context import get_context
 
@@ -28,7 +28,7 @@ class VocabParallelEmbedding(nn.Module):
     def forward(self, x: torch.Tensor):
         # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
         y = kernels.embed(x, self.weight.data, self.vocab_start_idx)
-        if self.tp_size > 1:
+        if collectives_on(self.tp_size):
             if get_comm() is not None:
                 return get_comm().all_reduce(y)
             tp_all_reduce(y)
@@ -58,7 +58,7 @@ class ParallelLMHead(VocabParallelEmbedding):
             last = (context.cu_seqlens_q[1:] - 1).long()
             x = x[last].contiguous()
         logits = kernels.gemm(x, self._streaming_weight())
-        if self.tp_size > 1:
+        if collectives_on(self.tp_size):
             gathered = tp_gather(logits, self.tp_rank, self.tp_size)
             logits = torch.cat(gathered, -1) if self.tp_rank == 0 else None
         return logits

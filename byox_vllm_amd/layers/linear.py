@@ -95,10 +95,21 @@ def copy_segments(dst: torch.Tensor, src: torch.Tensor, dim: int, segments) -> N
 _TP_STATE = None   # (rank, size, process group) once the runner has fixed the tensor-parallel layout
 
 
-def set_tp(rank: int, size: int, group=None) -> None:
-    """Fix the tensor-parallel layout explicitly (a data-parallel job has a process group but TP size 1)."""
-    global _TP_STATE
+_SINGLE_RANK_COLLECTIVES = False
+
+
+def set_tp(rank: int, size: int, group=None, single_rank_collectives: bool = False) -> None:
+    """Fix the tensor-parallel layout explicitly (a data-parallel job has a process group but TP size 1).
+    ``single_rank_collectives``: issue the row-parallel all-reduces, the embedding's all-reduce and the logits gather
+    even with one rank, so that a machine with a single GPU executes the RCCL calls of the tensor-parallel path
+    (sums over one rank: results unchanged)."""
+    global _TP_STATE, _SINGLE_RANK_COLLECTIVES
     _TP_STATE = (rank, size, group)
+    _SINGLE_RANK_COLLECTIVES = bool(single_rank_collectives) and size == 1
+
+
+def collectives_on(tp_size: int) -> bool:
+    return tp_size > 1 or _SINGLE_RANK_COLLECTIVES
 
 
 _COMM = None   # layers.comm.XgmiComm of this rank, or None: collectives then go through torch.distributed (RCCL)
@@ -343,12 +354,12 @@ class RowParallelLinear(LinearBase):
     def forward(self, x, out=None, partial_out=False):
         """partial_out (single rank only): return the split-K slabs for the following add_rmsnorm to sum."""
         bias = self.bias.data if (self.bias is not None and self.tp_rank == 0) else None
-        if partial_out and self.tp_size == 1 and bias is None:
+        if partial_out and not collectives_on(self.tp_size) and bias is None:
             return self._gemm(x, None, partial_out=True)
         if partial_out and self.tp_size > 1 and _COMM is not None:
             # the sum over ranks is taken by the consumer: the all-reduce fused with the following add-RMSNorm
             return kernels.PendingReduce(self._gemm(x, None, partial_out=True) if bias is None else self._gemm(x, bias))
         y = self._gemm(x, bias, out=out)
-        if self.tp_size > 1:
+        if collectives_on(self.tp_size):
             tp_all_reduce(y)
         return y
