@@ -72,6 +72,10 @@ if __name__ == "__main__":
         run_prefill(8, 1024, 28, 4, 128)
         run_prefill(2, 4096, 28, 4, 128)
         run_prefill(64, 128, 14, 2, 64)
+    elif which == "mall":     # working sets of 1, 2, 3 and 24 layers: does a cache-resident KV (256 MB Infinity Cache) stream faster?
+        for L in (1, 2, 3, 24):
+            print("layers cycled:", L)
+            run(128, 14, 2, 64, S, L, [1])
     elif which == "small":
         run(32, 14, 2, 64, 1024, 24, [1, 2, 4, 8])
         run(1, 14, 2, 64, 1024, 24, [1, 4, 8, 16])
