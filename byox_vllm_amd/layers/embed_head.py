@@ -21,9 +21,12 @@ class VocabParallelEmbedding(nn.Module):
         self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim), requires_grad=False)
         self.weight.weight_loader = self.weight_loader
 
+    loads = 0   # bumped by every load into any vocabulary matrix: derived layouts (the LM head's) are rebuilt after it
+
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
         shard = param.data.size(0)
         param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+        VocabParallelEmbedding.loads += 1
 
     def forward(self, x: torch.Tensor):
         # rows outside this rank's vocab shard come back as zeros, so the all-reduce assembles the embedding
@@ -43,14 +46,23 @@ class ParallelLMHead(VocabParallelEmbedding):
     def _streaming_weight(self) -> LinearWeight:
         """The vocabulary matrix in the layout nv_gemm streams fastest, built once per loaded weight.  The row-major
         parameter stays: it is what the checkpoint loader fills and what a tied embedding gathers from."""
-        w = self.weight.data
-        key = (w.data_ptr(), w._version)
         cached = getattr(self, "_tiled", None)
+        if self.weight is None:          # untied head whose row-major copy was released below
+            return cached[1]
+        w = self.weight.data
+        key = (w.data_ptr(), VocabParallelEmbedding.loads)
         if cached is None or cached[0] != key:
             n, k = w.shape
             packed = LinearWeight.dense_tiled(w) if (n % 16 == 0 and k % 128 == 0) else LinearWeight.dense(w)
             cached = self._tiled = (key, packed)
         return cached[1]
+
+    def release_row_major(self) -> None:
+        """An untied head needs only the streaming copy once the checkpoint is loaded (1.1 GB at Qwen2-7B); a tied
+        one shares its row-major storage with the embedding, which gathers from it."""
+        packed = self._streaming_weight()
+        if self.weight is not None and packed.data.data_ptr() != self.weight.data_ptr():
+            self.weight = None
 
     def forward(self, x: torch.Tensor):
         context = get_context()

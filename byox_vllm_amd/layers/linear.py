@@ -183,9 +183,10 @@ class LinearBase(nn.Module):
         self.packed: LinearWeight | None = None
 
     def finalize(self, quantization: str | None = None) -> None:
-        """Build the kernel-side weight; quantised layers free the dense parameter."""
+        """Build the kernel-side weight.  The row-major parameter is freed whenever the kernel-side weight is a copy of
+        it (quantised, or unquantised in the streaming layout): one copy of every matrix stays in device memory."""
         self.packed = self._pack(lambda t: t, quantization)
-        if quantization is not None:
+        if self.weight is not None and self.packed.data.data_ptr() != self.weight.data_ptr():
             self.weight = None
 
     def _pack(self, reorder, quantization):
@@ -294,7 +295,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         from byox_vllm_amd.layers.quant import interleave_gate_up
         self.fused_silu = fuse_silu and self.bias is None and len(self.output_sizes) == 2
         self.packed = self._pack(interleave_gate_up if self.fused_silu else (lambda t: t), quantization)
-        if quantization is not None or self.fused_silu:
+        if self.weight is not None and self.packed.data.data_ptr() != self.weight.data_ptr():
             self.weight = None
 
     def forward(self, x, out=None, partial_out=False):

@@ -181,3 +181,6 @@ class Qwen3ForCausalLM(nn.Module):
                 module.finalize(quantization, fuse_silu=True)
             elif isinstance(module, LinearBase):
                 module.finalize(quantization)
+        if self.lm_head.weight is not None and \
+                self.lm_head.weight.data_ptr() != self.model.embed_tokens.weight.data_ptr():
+            self.lm_head.release_row_major()
