@@ -55,6 +55,7 @@ _PROTOS = {
     "nv_sample_workspace_bytes": (_sz, [_i]),
     "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _p, _i, _p]),
     "nv_stage_decode_packed": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
+    "nv_stage_decode_packed_advance": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "nv_stage_decode_inputs": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
 }
 

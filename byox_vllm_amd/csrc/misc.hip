@@ -481,18 +481,39 @@ extern "C" int nv_stage_decode_inputs(const int64_t* ids, const int64_t* positio
 
 // Packed form of the staging above: ONE host->device copy carries the whole step
 // [ids | positions | slots | context_lens | temperature bits | block_tables], all as 32-bit words.
+// Advance form (header word 1 carries NV_STAGE_ADVANCE, prev_tokens given): the step continues the previous one for the
+// same rows, so nothing but the header is read from the host's buffer: every live row takes the token sampled for it
+// in the previous step, moves one position on, and derives its cache slot from the block table already on the device
+// (the bookkeeping of nanovllm/engine/model_runner.py:206-226, one step of it, without the host's lists).
 __global__ __launch_bounds__(256) void stage_packed_kernel(const int32_t* __restrict__ p, int bs, int padded, int bt_cols,
                                                            int64_t* g_ids, int64_t* g_pos, int32_t* g_slots,
                                                            int32_t* g_ctx, int32_t* g_bt, int g_bt_cols, float* g_temps,
-                                                           uint64_t* step_counter) {
+                                                           uint64_t* step_counter, const int64_t* prev_tokens,
+                                                           int block_size) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
   if (bs < 0) {  // header form: the batch size and table width of this step travel in the buffer itself
     bs = p[0];
     bt_cols = p[1];
     p += 2;
+    const bool advance = prev_tokens != nullptr && bt_cols >= 0 && (bt_cols & NV_STAGE_ADVANCE);
     bs = bs < 0 ? 0 : (bs > padded ? padded : bs);
+    if (advance) {
+      int cols = bt_cols & ~NV_STAGE_ADVANCE;   // the table width of the last full staging: columns past it are stale
+      cols = cols > g_bt_cols ? g_bt_cols : cols;
+      for (int i = tid; i < bs; i += nthr) {
+        const int64_t pos = g_pos[i] + 1;
+        const int col = (int)(pos / block_size);
+        const int32_t blk = col < cols ? g_bt[(int64_t)i * g_bt_cols + col] : -1;
+        g_ids[i] = prev_tokens[i];
+        g_pos[i] = pos;
+        g_ctx[i] += 1;
+        g_slots[i] = blk >= 0 ? blk * block_size + (int32_t)(pos - (int64_t)col * block_size) : -1;
+      }
+      if (tid == 0 && step_counter) step_counter[0] += 1;
+      return;
+    }
     bt_cols = bt_cols < 0 ? 0 : (bt_cols > g_bt_cols ? g_bt_cols : bt_cols);
   }
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
   for (int i = tid; i < padded; i += nthr) {
     const bool live = i < bs;
     g_ids[i] = live ? p[i] : 0;
@@ -509,10 +530,32 @@ __global__ __launch_bounds__(256) void stage_packed_kernel(const int32_t* __rest
   if (tid == 0 && step_counter) step_counter[0] += 1;
 }
 
+static int stage_packed_go(const int32_t* packed, int bs, int padded_bs, int bt_cols, int64_t* g_ids,
+                           int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens, int32_t* g_block_tables,
+                           int g_bt_cols, float* g_temperatures, uint64_t* step_counter, const int64_t* prev_tokens,
+                           int block_size, nv_stream_t stream);
+
 extern "C" int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_cols, int64_t* g_ids,
                                       int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens,
                                       int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,
                                       uint64_t* step_counter, nv_stream_t stream) {
+  return stage_packed_go(packed, bs, padded_bs, bt_cols, g_ids, g_positions, g_slots, g_context_lens, g_block_tables,
+                         g_bt_cols, g_temperatures, step_counter, nullptr, 0, stream);
+}
+
+extern "C" int nv_stage_decode_packed_advance(const int32_t* packed, int padded_bs, int64_t* g_ids, int64_t* g_positions,
+                                              int32_t* g_slots, int32_t* g_context_lens, int32_t* g_block_tables,
+                                              int g_bt_cols, float* g_temperatures, uint64_t* step_counter,
+                                              const int64_t* prev_tokens, int block_size, nv_stream_t stream) {
+  NV_CHECK_ARG(prev_tokens && block_size > 0, "nv_stage_decode_packed_advance: prev_tokens and block_size are required");
+  return stage_packed_go(packed, -1, padded_bs, 0, g_ids, g_positions, g_slots, g_context_lens, g_block_tables,
+                         g_bt_cols, g_temperatures, step_counter, prev_tokens, block_size, stream);
+}
+
+static int stage_packed_go(const int32_t* packed, int bs, int padded_bs, int bt_cols, int64_t* g_ids,
+                           int64_t* g_positions, int32_t* g_slots, int32_t* g_context_lens, int32_t* g_block_tables,
+                           int g_bt_cols, float* g_temperatures, uint64_t* step_counter, const int64_t* prev_tokens,
+                           int block_size, nv_stream_t stream) {
   NV_CHECK_ARG(packed && g_ids && g_positions && g_slots && g_context_lens && g_block_tables,
                "nv_stage_decode_packed: null pointer");
   NV_CHECK_ARG(bs < 0 || (padded_bs >= bs && bt_cols >= 0 && bt_cols <= g_bt_cols),
@@ -527,7 +570,7 @@ extern "C" int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_
   if (blocks > 64) blocks = 64;
   stage_packed_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(
       packed, bs, padded_bs, bt_cols, g_ids, g_positions, g_slots, g_context_lens, g_block_tables, g_bt_cols,
-      g_temperatures, step_counter);
+      g_temperatures, step_counter, prev_tokens, block_size);
   NV_CHECK_LAUNCH();
   return NV_OK;
 }

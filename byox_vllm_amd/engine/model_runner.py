@@ -48,6 +48,7 @@ class ModelRunner:
             config.tensor_parallel_size > 1 and os.environ.get("NV_DIST_BACKEND", "nccl") != "nccl"
             and not self.use_xgmi)
         self.world_size = config.tensor_parallel_size
+        self.device_bookkeeping = os.environ.get("NV_DEVICE_BOOKKEEPING", "1") != "0"
         self.rank = rank
         self.event = event
         if not torch.cuda.is_available():
@@ -198,12 +199,39 @@ class ModelRunner:
         bs = len(seqs)
         g = self.graph_vars
         host = self._host_stage_np
-        n, cols = self._pack_decode(seqs, host[2:])
-        host[0], host[1] = bs, cols          # header read on the device by the graph's own staging node
-        padded = g["padded_bs"] = next(x for x in self.graph_bs if x >= bs)
+        padded = next(x for x in self.graph_bs if x >= bs)
+        ntok = self._continues_previous_step(seqs, padded)
+        cache = getattr(self, "_pack_cache", None)
+        if ntok is not None:                 # the device advances its own copy of the step: only the header travels
+            host[0], host[1] = bs, cache["key"][1] | kernels.STAGE_ADVANCE
+        else:
+            n, cols = self._pack_decode(seqs, host[2:])
+            host[0], host[1] = bs, cols      # header read on the device by the graph's own staging node
+            cache = self._pack_cache
+            ntok = cache["ntok"].tolist()
+        g["padded_bs"] = padded
         self._replay(padded)
         torch.cuda.current_stream().synchronize()
-        return self._host_tokens_np[:bs].tolist()
+        tokens = self._host_tokens_np[:bs].tolist()
+        cache["padded"], cache["tokens"], cache["next_ntok"] = padded, tokens, [x + 1 for x in ntok]
+        return tokens
+
+    def _continues_previous_step(self, seqs: list[Sequence], padded: int):
+        """The sequences' lengths when this decode step is the previous graph step continued: the same Sequence objects
+        in the same order, every one longer by exactly the token this runner returned for it, no block table touched
+        (Sequence.table_epoch, total block count) and the same captured graph; None otherwise.  The device then holds
+        everything the step needs (nv_stage_decode_packed_advance) and the host builds no arrays at all."""
+        cache = getattr(self, "_pack_cache", None)
+        if (not self.device_bookkeeping or cache is None or cache.get("tokens") is None or cache["padded"] != padded
+                or cache["seqs"] != seqs or cache["key"] is None or cache["key"][2] != Sequence.table_epoch):
+            return None
+        total = 0
+        for seq in seqs:
+            total += len(seq.block_table)
+        ntok = [seq.num_tokens for seq in seqs]
+        if total != cache["key"][0] or ntok != cache["next_ntok"] or [seq.last_token for seq in seqs] != cache["tokens"]:
+            return None
+        return ntok
 
     def _pack_decode(self, seqs: list[Sequence], host: np.ndarray) -> tuple[int, int]:
         """Fill ``host`` (int32) with one decode step's integers, laid out as nv_stage_decode_packed reads them:
@@ -223,13 +251,15 @@ class ModelRunner:
         ntok = head[3]
         ntok[:] = [seq.num_tokens for seq in seqs]
         np.subtract(ntok, 1, out=head[1])
+        ntok_copy = ntok.copy()
         # Steady-state decode presents the same Sequence objects step after step: what cannot change for a given
         # object (its temperature) and what rarely changes (the padded tables, the last block of every row) is kept
         # from the previous step.  List equality short-cuts on identity, so the checks cost well under a microsecond.
         cached = getattr(self, "_pack_cache", None)
         if cached is None or cached["seqs"] != seqs:
-            cached = self._pack_cache = {"seqs": list(seqs), "key": None,
+            cached = self._pack_cache = {"seqs": list(seqs), "key": None, "tokens": None,
                                          "temps": np.array([seq.temperature for seq in seqs], dtype=np.float32)}
+        cached["ntok"] = ntok_copy
         host[4 * bs:5 * bs].view(np.float32)[:] = cached["temps"]
         tables = host[5 * bs:n].reshape(bs, cols)
         key = (total, cols, Sequence.table_epoch)
@@ -423,7 +453,8 @@ class ModelRunner:
             """Decode forward (+ LM head + sampler on a single rank) for rows [0, bs) of the static buffers."""
             if stage_words:
                 self._dev_stage[:stage_words].copy_(self._host_stage[:stage_words], non_blocking=True)
-                kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
+                kernels.stage_decode_packed(self._dev_stage, -1, 0, g, prev_tokens=g["tokens"],
+                                            block_size=self.block_size)
             self._set_decode_splits(bs)
             set_context(False, slot_mapping=g["slot_mapping"][:bs], context_lens=g["context_lens"][:bs],
                         block_tables=g["block_tables"][:bs])

@@ -296,8 +296,19 @@ def stage_decode_inputs(ids, positions, slots, context_lens, block_tables, g):
                                        bs, padded, stream()), "nv_stage_decode_inputs")
 
 
-def stage_decode_packed(packed, bs, bt_cols, g):
-    """Unpack one step's host buffer (already copied to the device) into the static graph buffers ``g``."""
+STAGE_ADVANCE = 0x40000000   # header word 1 of the packed buffer: continue the previous step on the device
+
+
+def stage_decode_packed(packed, bs, bt_cols, g, prev_tokens=None, block_size=0):
+    """Unpack one step's host buffer (already copied to the device) into the static graph buffers ``g``.
+    ``prev_tokens`` (header form only): the launch also honours the STAGE_ADVANCE flag of the header."""
+    if prev_tokens is not None:
+        assert bs < 0 and prev_tokens.dtype == torch.int64 and block_size > 0
+        check(lib().nv_stage_decode_packed_advance(
+            ptr(packed), g["padded_bs"], ptr(g["input_ids"]), ptr(g["positions"]), ptr(g["slot_mapping"]),
+            ptr(g["context_lens"]), ptr(g["block_tables"]), g["block_tables"].size(1), ptr(g.get("temperatures")),
+            ptr(g.get("step")), ptr(prev_tokens), block_size, stream()), "nv_stage_decode_packed_advance")
+        return
     check(lib().nv_stage_decode_packed(ptr(packed), bs, g["padded_bs"], bt_cols, ptr(g["input_ids"]),
                                        ptr(g["positions"]), ptr(g["slot_mapping"]), ptr(g["context_lens"]),
                                        ptr(g["block_tables"]), g["block_tables"].size(1), ptr(g.get("temperatures")),

@@ -224,6 +224,22 @@ int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_
                            int32_t* g_block_tables, int g_bt_cols, float* g_temperatures,
                            uint64_t* step_counter, nv_stream_t stream);
 
+/* The header form with device-side bookkeeping.  When header word 1 has NV_STAGE_ADVANCE set, the step continues
+ * the previous one for the same rows and nothing else is read from the buffer: for every row i < bs
+ *   ids[i] = prev_tokens[i] (the token sampled for the row in the previous step), positions[i] += 1,
+ *   context_lens[i] += 1, slots[i] = block_tables[i][positions[i] / block_size] * block_size + positions[i] % block_size
+ *   (-1 when that table entry is negative or past g_bt_cols)
+ * which is one step of the per-sequence arithmetic of ModelRunner.prepare_decode (model_runner.py:206-226) done on
+ * the device from the tables the previous full staging left there; block tables and temperatures stay.  Without the
+ * flag the call is nv_stage_decode_packed's header form.  The host decides per step which form applies (same rows, each
+ * one token longer by exactly the token returned, no block table changed) by setting the flag in the pinned buffer,
+ * so one captured launch serves both. */
+#define NV_STAGE_ADVANCE 0x40000000
+int nv_stage_decode_packed_advance(const int32_t* packed, int padded_bs, int64_t* g_ids, int64_t* g_positions,
+                                   int32_t* g_slots, int32_t* g_context_lens, int32_t* g_block_tables, int g_bt_cols,
+                                   float* g_temperatures, uint64_t* step_counter, const int64_t* prev_tokens,
+                                   int block_size, nv_stream_t stream);
+
 /* ---- all-reduce over peer-mapped device memory (xGMI), fused with the residual add and RMSNorm that follow it.
  * Replaces dist.all_reduce after RowParallelLinear (nanovllm/layers/linear.py:145-146) and after the vocab-parallel
  * embedding (layers/embed_head.py:38-40) together with the add_rms_forward that consumes the sum

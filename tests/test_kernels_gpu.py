@@ -755,6 +755,47 @@ def test_stage_decode_packed_plain_and_header_form():
     assert g["context_lens"].cpu().tolist() == [0] * 8 and g["block_tables"].cpu().eq(0).all()
 
 
+def test_stage_decode_advance_continues_the_previous_step_on_the_device():
+    """Header flag NV_STAGE_ADVANCE: ids <- the previous step's tokens, positions and context lengths + 1, slots from
+    the block tables already on the device (what ModelRunner.prepare_decode computes per sequence,
+    model_runner.py:206-226), rows past bs and everything else untouched; without the flag the same launch stages
+    the packed buffer."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.engine.model_runner import ModelRunner
+    from byox_vllm_amd.engine.sequence import Sequence
+    padded, gcols, block = 8, 5, 16
+    g = dict(input_ids=dev(torch.zeros(8, dtype=torch.int64)), positions=dev(torch.zeros(8, dtype=torch.int64)),
+             slot_mapping=dev(torch.zeros(8, dtype=torch.int32)), context_lens=dev(torch.zeros(8, dtype=torch.int32)),
+             block_tables=dev(torch.zeros((8, gcols), dtype=torch.int32)), temperatures=dev(torch.zeros(8)),
+             step=dev(torch.zeros(1, dtype=torch.int64)), padded_bs=padded)
+    prev = dev(torch.tensor([101, 102, 103, 104, 0, 0, 0, 0], dtype=torch.int64))
+    # four sequences: mid-block, last position of a block, first position of the next (allocated) block, and one
+    # whose next position falls into a block the table does not hold yet (-1 padding)
+    lens = [5, 31, 32, 48]
+    tables = [[3, -1, -1], [4, 5, -1], [6, 7, 8], [9, 10, 11]]
+    temps = np.array([0.5, 1.0, 0.0, 0.7], dtype=np.float32)
+    payload = np.concatenate([[3, gcols - 2], [11, 12, 13, 14], [n - 1 for n in lens],
+                              [tables[i][(n - 1) // block] * block + (n - 1) % block for i, n in enumerate(lens)], lens,
+                              temps.view(np.int32), np.array(tables).reshape(-1)]).astype(np.int32)
+    payload[0] = 4
+    buf = dev(torch.from_numpy(payload.copy()))
+    kernels.stage_decode_packed(buf, -1, 0, g, prev_tokens=prev, block_size=block)
+    assert g["input_ids"].cpu().tolist()[:4] == [11, 12, 13, 14] and g["step"].item() == 1
+    before_tables = g["block_tables"].cpu().clone()
+    header_only = payload.copy()
+    header_only[1] |= kernels.STAGE_ADVANCE
+    header_only[2:] = 777                    # nothing behind the header may be read
+    buf.copy_(torch.from_numpy(header_only))
+    kernels.stage_decode_packed(buf, -1, 0, g, prev_tokens=prev, block_size=block)
+    want_pos = lens                           # the new token's position = the old length
+    assert g["input_ids"].cpu().tolist() == [101, 102, 103, 104, 0, 0, 0, 0]
+    assert g["positions"].cpu().tolist() == want_pos + [0] * 4
+    assert g["context_lens"].cpu().tolist() == [n + 1 for n in lens] + [0] * 4
+    assert g["slot_mapping"].cpu().tolist() == [3 * 16 + 5, 5 * 16 + 15, 8 * 16 + 0, -1, -1, -1, -1, -1]
+    assert torch.equal(g["block_tables"].cpu(), before_tables) and g["temperatures"].cpu().tolist()[:4] == temps.tolist()
+    assert g["step"].item() == 2
+
+
 def test_bad_arguments_are_rejected_not_launched():
     from byox_vllm_amd import kernels
     from byox_vllm_amd.layers.quant import LinearWeight

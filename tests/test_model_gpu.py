@@ -275,3 +275,46 @@ def test_graph_replay_equals_eager(golden):
         outs.append(toks)
         runner.exit()
     assert outs[0] == outs[1]
+
+
+def test_device_side_bookkeeping_equals_host_packing(golden, monkeypatch):
+    """Decode steps continued on the device (ids from the previous step's tokens, positions + 1, slots from the device's
+    block tables) against the same steps packed on the host every time: identical tokens over block boundaries, a
+    batch that shrinks, and a step the host has to re-pack because a table grew."""
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    from byox_vllm_amd.engine.block_manager import BlockManager
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+    outs, advanced = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NV_DEVICE_BOOKKEEPING", mode)
+        runner = make_runner(cfg, weights, enforce_eager=False, max_num_seqs=8, num_blocks=32)
+        assert runner.device_bookkeeping == (mode == "1")
+        count = [0]
+
+        def counted(seqs_, padded, real=runner._continues_previous_step, count=count):
+            result = real(seqs_, padded)
+            count[0] += result is not None
+            return result
+        runner._continues_previous_step = counted
+        bm = BlockManager(32, BS)
+        rng = np.random.RandomState(9)
+        seqs = [Sequence(rng.randint(0, 256, size=n).tolist(), BS, SamplingParams(temperature=0.0, max_tokens=64))
+                for n in (5, BS - 2, 2 * BS - 1, 33)]
+        for s in seqs:
+            bm.allocate(s)
+        toks = [runner.run(seqs, True)]
+        for step in range(2 * BS + 3):
+            for s, tkn in zip(seqs, toks[-1]):
+                s.append_token(tkn)
+                bm.may_append(s)
+            if step == BS:                   # one sequence leaves the batch
+                bm.deallocate(seqs.pop(1))
+                toks[-1] = toks[-1][:1] + toks[-1][2:]
+            toks.append(runner.run(seqs, False))
+        outs.append(toks)
+        advanced.append(count[0])
+        runner.exit()
+    assert outs[0] == outs[1]
+    assert advanced[1] == 0 and advanced[0] >= BS, advanced   # most steps cross no block boundary
