@@ -289,8 +289,8 @@ extern "C" int nv_comm_init(nv_comm** comm, int rank, int world, int max_rows, i
       (void)hipGetLastError();
       c->memory_kind = 0;
       if (hipMalloc(&base, c->bytes) != hipSuccess) {
-        delete c;
         nv_set_error("nv_comm_init: cannot allocate %zu bytes", c->bytes);
+        delete c;
         return NV_ERR_LAUNCH;
       }
     }
