@@ -99,7 +99,7 @@ def step_bytes(runner, seqs, hf, tp):
     """Algorithmic HBM bytes of one whole decode step on this GPU (weights + scales + LM head + KV read/write)."""
     from byox_vllm_amd.layers.linear import LinearBase
     w = sum(m.packed.nbytes for m in runner.model.modules() if isinstance(m, LinearBase))
-    head = runner.model.lm_head.weight.numel() * hf.dtype.itemsize
+    head = runner.model.lm_head._streaming_weight().nbytes   # an untied head keeps only its streaming copy
     kv_read = kv_bytes_per_launch(seqs, hf, tp) * hf.num_hidden_layers
     kv_write = len(seqs) * hf.num_hidden_layers * 2 * max(1, hf.num_key_value_heads // tp) * hf.head_dim * hf.dtype.itemsize
     return w + head + kv_read + kv_write

@@ -33,11 +33,14 @@ struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
+  int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);
 void nv_gemm_reduce_bf16(const GemmArgs& a);
 void nv_gemm_reduce_f16(const GemmArgs& a);
+void nv_gemm_wide_launch_bf16(const GemmArgs& a);
+void nv_gemm_wide_launch_f16(const GemmArgs& a);
 
 extern "C" size_t nv_gemm_workspace_bytes(int64_t M, int N, int split_k) {
   if (split_k < 1) split_k = 1;
@@ -147,7 +150,19 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.rope = RopeArgs{};
   a.stream = (hipStream_t)stream;
-  if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
+  // Where the planner wants 128 rows x 192 columns per workgroup of int4 weights, the 32x32x16 kernel covers the same
+  // tile with its conversion work hidden under the MFMAs (gemm_wide.h); NV_GEMM_WIDE=1 / 0 forces it on (where the
+  // shape allows) / off.
+  a.wide = 0;
+  if (wfmt == NV_W_INT4 && M > 64 && N % 32 == 0) {
+    a.wide = a.ntw == 3 && a.bm == 128;
+    if (const char* e = getenv("NV_GEMM_WIDE")) a.wide = atoi(e) == 1;   // measurement aid
+  }
+  if (a.wide) {
+    if (dtype == NV_BF16) nv_gemm_wide_launch_bf16(a); else nv_gemm_wide_launch_f16(a);
+  } else {
+    if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
+  }
   NV_CHECK_LAUNCH();
   if (use_slabs && !slabs_out) {
     if (dtype == NV_BF16) nv_gemm_reduce_bf16(a); else nv_gemm_reduce_f16(a);
@@ -218,6 +233,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   NV_CHECK_ARG(M >= 0, "nv_gemm_rope_kv_store: M=%lld", (long long)M);
   if (M == 0) return NV_OK;
   GemmArgs a;
+  a.wide = 0;
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
   a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;
   a.bm = rope_fused_plan(M, K, wfmt, H + 2 * Hkv, D, nullptr);

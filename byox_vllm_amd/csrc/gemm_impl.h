@@ -475,6 +475,7 @@ struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
+  int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 #endif
 

@@ -13,7 +13,8 @@ def run(name, M, N, K, fmt, L, split_k=None, silu=False, partial=False, dt=torch
     for _ in range(L):
         w = LinearWeight(base.fmt, base.data.clone(), None if base.scales is None else base.scales.clone(), N, K, dt)
         ws.append(w)
-    x = torch.randn(M, K, device=dev).to(dt)
+    pad = int(os.environ.get("NV_BENCH_X_PAD", "0"))      # extra elements per row of x: a row stride that is not a
+    x = torch.randn(M, K + pad, device=dev).to(dt)[:, :K]  # multiple of 4 KB spreads the tile over the L2 channels
     out = torch.empty(M, N // 2 if silu else N, device=dev, dtype=dt)
     def call(w):
         return kernels.gemm(x, w, out=None if partial else out, split_k=split_k, silu_mul=silu, partial_out=partial)

@@ -10,6 +10,7 @@
 #include <algorithm>
 void nv_set_error(const char*, ...) {}
 #include "../../byox_vllm_amd/csrc/gemm_impl.h"
+#include "../../byox_vllm_amd/csrc/gemm_wide.h"
 
 #ifndef PROBE_NTW
 #define PROBE_NTW 3
@@ -36,6 +37,10 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> hs(sbytes / 2), hx((size_t)M * K);
   for (auto& v : hs) { r = r * 1664525u + 1013904223u; v = 0x3c00 + (r >> 26); }   // bf16 ~0.0078..0.0156
   for (auto& v : hx) { r = r * 1664525u + 1013904223u; v = (uint16_t)((r >> 16) & 0xbfff) | 0x3000; v &= 0xbf7f; }
+  if (getenv("PROBE_ZERO")) {   // all-zero operands: the same instruction stream at the lowest switching activity
+    std::fill(hw.begin(), hw.end(), 0x88888888u);
+    std::fill(hx.begin(), hx.end(), (uint16_t)0);
+  }
   std::vector<void*> dw(copies), ds(copies);
   for (int c = 0; c < copies; ++c) {
     CK(hipMalloc(&dw[c], wbytes)); CK(hipMalloc(&ds[c], sbytes));
@@ -49,11 +54,20 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&dpart, pbytes)); CK(hipMemset(dpart, 0, pbytes));
   const int ntiles = N / 16, per_block = 4 * PROBE_NTW;
   dim3 grid((ntiles + per_block - 1) / per_block, (M + PROBE_BM - 1) / PROBE_BM, split);
+#ifdef PROBE_WIDE   // the 32x32x16 kernel: 192 columns per workgroup, 768 threads
+  grid = dim3((N / 32 + GEMM_WIDE_NCG - 1) / GEMM_WIDE_NCG, (M + 127) / 128, split);
+  auto launch = [&](int c) {
+    gemm_wide_w4_kernel<bf16_t, PROBE_EPI><<<grid, dim3(GEMM_WIDE_THREADS)>>>(
+        (const uint16_t*)dx, K, dw[c], (const uint16_t*)ds[c], nullptr, (uint16_t*)dout, PROBE_EPI == 1 ? N / 2 : N,
+        dpart, M, N, K, split);
+  };
+#else
   auto launch = [&](int c) {
     gemm_kernel<bf16_t, PROBE_WFMT, PROBE_BM, PROBE_NTW, PROBE_EPI><<<grid, dim3(512)>>>(
         (const uint16_t*)dx, K, dw[c], (const uint16_t*)ds[c], nullptr, (uint16_t*)dout, PROBE_EPI == 1 ? N / 2 : N,
         dpart, M, N, K, split, RopeArgs{});
   };
+#endif
   for (int c = 0; c < copies; ++c) launch(c);
   CK(hipDeviceSynchronize());
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));

