@@ -321,7 +321,15 @@ def main():
                         max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
                         enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0,
                         xgmi_allreduce=tp_size > 1 and args.allreduce == "xgmi")
-        r = ModelRunner(config, rank if tp_size > 1 else 0, None)
+        try:
+            r = ModelRunner(config, rank if tp_size > 1 else 0, None)
+        except Exception as e:   # a collective that cannot be captured on this stack must not cost the whole measurement
+            if tp_size == 1 or config.enforce_eager:
+                raise
+            print(f"[bench] rank {rank}: capturing the tensor-parallel decode graph failed ({e!r}); running the step "
+                  "eagerly (graph_captured: false)", file=sys.stderr, flush=True)
+            config.enforce_eager = True
+            r = ModelRunner(config, rank, None)
         r.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
         seqs_, next_block = make_sequences(batch, context, block_size)
         return r, seqs_, StepDriver(r, seqs_, next_block, tp_size)
