@@ -142,3 +142,39 @@ def test_fuzz_gemm(seed):
     assert got.shape == want.shape
     bad = (got - want).abs() > ulps * eps * want.abs().clamp_min(1e-3) * 2   # same bar as the kernel tests' ulp_close
     assert not bad.any(), (M, N, K, fmt, silu, int(bad.sum()), (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_gemm_wide_int4_kernel(seed, monkeypatch):
+    """The 32x32x16 int4 kernel forced on random shapes it admits (more than 64 rows, N a multiple of 32): ragged rows,
+    ragged last column group, K splits down to one K-block per workgroup, every epilogue, both dtypes."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    from oracle import layers as L
+    from oracle import quant as Q
+    monkeypatch.setenv("NV_GEMM_WIDE", "1")
+    rng = np.random.RandomState(1700 + seed)
+    name = "bf16" if seed % 3 else "fp16"
+    dt = DT[name]
+    M = int(rng.choice([65, 100, 128, 129, 200, 300, 515]))
+    N = 32 * int(rng.randint(1, 24))
+    K = 128 * int(rng.randint(1, 9))
+    silu = seed % 4 == 0 and N % 64 == 0
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    w_ref = Q.dequantize_w4(*Q.quantize_w4(w))
+    lw = LinearWeight.make(interleave_gate_up(dev(w)) if silu else dev(w), "w4a16")
+    eps = 2.0 ** -8 if name == "bf16" else 2.0 ** -11
+    if silu:
+        want = L.silu_and_mul(L.linear(x, w_ref)).float()
+        got = kernels.gemm(dev(x), lw, silu_mul=True).float().cpu()
+        ulps = 2.0
+    else:
+        bias = (torch.randn(N, generator=g) * 0.1).to(dt)
+        want = torch.nn.functional.linear(x.double(), w_ref.double(), bias.double()).to(dt).float()
+        got = kernels.gemm(dev(x), lw, dev(bias), split_k=int(rng.randint(1, 9))).float().cpu()
+        ulps = 1.0
+    assert got.shape == want.shape
+    bad = (got - want).abs() > ulps * eps * want.abs().clamp_min(1e-3) * 2
+    assert not bad.any(), (M, N, K, silu, int(bad.sum()), (got - want).abs().max().item())
