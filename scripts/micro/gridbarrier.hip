@@ -37,6 +37,37 @@ __global__ __launch_bounds__(512) void meet2(unsigned* cnt /* [8 * 32] class cou
   sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// Flag-array form, no read-modify-write at all: workgroup b stores the phase number into its own word flags[b]
+// (write-through), and the first wavefront of every workgroup polls ALL words, lane l reading flags[l], flags[l + 64],
+// ...: one vector load per 64 workgroups and poll, no serialisation of arrivals at one address.
+__global__ __launch_bounds__(512) void meet3(unsigned* flags, unsigned* err, int iters, int work, float* sink) {
+  float acc = threadIdx.x;
+  const int G = gridDim.x;
+  for (int it = 0; it < iters; ++it) {
+    for (int w = 0; w < work; ++w) acc = acc * 1.0001f + 0.5f;
+    __syncthreads();
+    if (threadIdx.x < 64 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      const unsigned phase = (unsigned)(it + 1);
+      if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], phase, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      for (;;) {
+        bool ok = true;
+        for (int b = threadIdx.x; b < G; b += 64)
+          ok = ok && __hip_atomic_load(&flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 18)) {
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(512) void meet(unsigned* counter, unsigned* err, int iters, int work, float* sink) {
   float acc = threadIdx.x;
   for (int it = 0; it < iters; ++it) {
@@ -98,6 +129,24 @@ int main() {
     }
     unsigned e; hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost);
     printf("two-level, grid %3d x 512: %.2f us per barrier%s\n", G, (ms[1] - ms[0]) * 1000.0 / 1000.0, e ? "  (TIMED OUT)" : "");
+  }
+  unsigned* flags;
+  hipMalloc(&flags, 512 * 4);
+  const int grids3[] = {16, 64, 112, 256};
+  for (int gi = 0; gi < 4; ++gi) {
+    const int G = grids3[gi];
+    float ms[2];
+    for (int pass = 0; pass < 2; ++pass) {
+      const int iters = pass == 0 ? 100 : 1100;
+      hipMemset(flags, 0, 512 * 4); hipMemset(err, 0, 4);
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      hipEventRecord(a);
+      meet3<<<G, 512>>>(flags, err, iters, 0, sink);
+      hipEventRecord(b); hipEventSynchronize(b);
+      hipEventElapsedTime(&ms[pass], a, b);
+    }
+    unsigned e; hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost);
+    printf("flag array, grid %3d x 512: %.2f us per barrier%s\n", G, (ms[1] - ms[0]) * 1000.0 / 1000.0, e ? "  (TIMED OUT)" : "");
   }
   return 0;
 }
