@@ -299,3 +299,61 @@ def test_pack_decode_matches_prepare_functions_and_tracks_table_changes():
     check()
     seqs.reverse()                           # same size, other rows: per-row temperatures must follow
     check()
+
+
+def test_continues_previous_step_decision():
+    """When may a decode step be derived on the device from the previous one (NV_STAGE_ADVANCE)?  Only if the same
+    Sequence objects come back in the same order, each longer by exactly the token returned for it, with no block
+    table touched and the same captured graph; the host logic that decides it, without a GPU."""
+    import numpy as np
+    from byox_vllm_amd.sampling_params import SamplingParams
+
+    runner = ModelRunner.__new__(ModelRunner)
+    runner.block_size, runner.device, runner.device_bookkeeping = 16, torch.device("cpu"), True
+    bm = BlockManager(64, 16)
+    seqs = [Sequence(list(range(100, 100 + n)), 16, SamplingParams(temperature=0.7)) for n in (5, 14, 20)]
+    for s in seqs:
+        bm.allocate(s)
+    host = np.zeros(1024, dtype=np.int32)
+
+    def full_step(tokens, padded=4):       # what _run_decode_graph records after a step packed on the host
+        runner._pack_decode(seqs, host)
+        c = runner._pack_cache
+        c["padded"], c["tokens"], c["next_ntok"] = padded, list(tokens), [n + 1 for n in c["ntok"].tolist()]
+
+    def advance(tokens):                    # ... and after a step continued on the device
+        c = runner._pack_cache
+        c["tokens"], c["next_ntok"] = list(tokens), [n + 1 for n in c["next_ntok"]]
+
+    def scheduler_appends(tokens):
+        for s, t in zip(seqs, tokens):
+            s.append_token(t)
+            bm.may_append(s)
+
+    assert runner._continues_previous_step(seqs, 4) is None            # nothing ran yet
+    full_step([7, 8, 9])
+    assert runner._continues_previous_step(seqs, 4) is None            # the sequences did not move
+    scheduler_appends([7, 8, 9])
+    assert runner._continues_previous_step(seqs, 4) == [6, 15, 21]
+    assert runner._continues_previous_step(seqs, 8) is None            # another captured graph
+    advance([1, 2, 3])
+    scheduler_appends([1, 2, 3])                                       # the second sequence reaches 16 tokens: no new block yet
+    assert runner._continues_previous_step(seqs, 4) == [7, 16, 22]
+    advance([4, 5, 6])
+    scheduler_appends([4, 5, 6])                                       # 17 tokens: may_append allocated a block
+    assert runner._continues_previous_step(seqs, 4) is None
+    full_step([1, 1, 1])                                               # re-packed on the host; it returned 1, 1, 1
+    scheduler_appends([1, 1, 1])
+    assert runner._continues_previous_step(seqs, 4) is not None
+    seqs[0].token_ids[-1] = 99                                         # not the token the runner returned
+    seqs[0].last_token = 99
+    assert runner._continues_previous_step(seqs, 4) is None
+    seqs[0].token_ids[-1] = seqs[0].last_token = 1
+    assert runner._continues_previous_step(seqs, 4) is not None
+    assert runner._continues_previous_step(list(reversed(seqs)), 4) is None     # other order
+    assert runner._continues_previous_step(seqs[:2], 4) is None                 # other batch
+    seqs[2].block_table.append(60)                                              # a table edited by hand
+    assert runner._continues_previous_step(seqs, 4) is None
+    seqs[2].block_table.pop()
+    runner.device_bookkeeping = False
+    assert runner._continues_previous_step(seqs, 4) is None
