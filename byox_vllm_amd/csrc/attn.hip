@@ -264,7 +264,7 @@ __device__ __forceinline__ int64_t paged_tile_row(const int32_t* bt_row, int tok
 // NW wavefronts per workgroup share one (sequence, kv head, split); wavefront w takes chunks
 // split*NW + w, + NW*splits, ...  Loads run one chunk ahead of the MFMAs and block-table lookups two ahead.
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
+__global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, const int32_t* __restrict__ block_tables, int bt_stride,
     const int32_t* __restrict__ context_lens, uint16_t* __restrict__ out, int64_t out_stride,
@@ -390,66 +390,85 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_kernel(
     }
   }
 
-  // ---- merge the NW wavefronts of the workgroup
+  // ---- merge the NW wavefronts of the workgroup.  The first NF = min(NW, 4) wavefronts finish the accumulator
+  // register indices r = wid, wid + NF, ...: d = NM * (4g + r) + m, m = 0..NM-1 contiguous.  A single wavefront
+  // has nothing to merge and keeps everything in registers.
+  constexpr int NF = NW < 4 ? NW : 4;
   float l = st.l;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  if (g == 0) {
-    s_m[wid][c] = st.m;
-    s_l[wid][c] = l;
-  }
+  float M, L, f[NW];
+  if constexpr (NW == 1) {
+    M = st.m;
+    L = l;
+    f[0] = 1.f;
+  } else {
+    if (g == 0) {
+      s_m[wid][c] = st.m;
+      s_l[wid][c] = l;
+    }
 #pragma unroll
-  for (int m = 0; m < NM; ++m)
+    for (int m = 0; m < NM; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s_acc[wid][m * 4 + r][lane] = st.acc[m][r];
-  __syncthreads();
-  if (wid >= 4) return;   // the first four wavefronts finish one accumulator register index each
-
-  float M = -INFINITY;
+      for (int r = 0; r < 4; ++r) s_acc[wid][m * 4 + r][lane] = st.acc[m][r];
+    __syncthreads();
+    if (wid >= NF) return;
+    M = -INFINITY;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][c]);
-  float f[NW], L = 0.f;
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, s_m[w][c]);
+    L = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const float mw = s_m[w][c];
-    f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
-    L += s_l[w][c] * f[w];
-  }
-  // wavefront `wid` finishes register r = wid of every m: d = NM*(4g + wid) + m, m = 0..NM-1 contiguous
-  float o[NM];
-#pragma unroll
-  for (int m = 0; m < NM; ++m) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += s_acc[w][m * 4 + wid][lane] * f[w];
-    o[m] = v;
+    for (int w = 0; w < NW; ++w) {
+      const float mw = s_m[w][c];
+      f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
+      L += s_l[w][c] * f[w];
+    }
   }
   if (c >= G) return;
   const int head = kvh * G + c;
-  const int d0 = NM * (4 * g + wid);
-  if (splits == 1) {
-    const float inv = (L > 0.f) ? 1.0f / L : 0.f;
-    uint16_t* dst = out + (int64_t)b * out_stride + (int64_t)head * D + d0;
-    if constexpr (NM == 8) {
-      u32x4 w;
+  const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+  const int64_t slot = ((int64_t)b * H + head) * splits + split;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
-      *reinterpret_cast<u32x4*>(dst) = w;
+  for (int rr = 0; rr < 4 / NF; ++rr) {
+    float o[NM];
+    int d0;
+    if constexpr (NW == 1) {
+      d0 = NM * (4 * g + rr);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) o[m] = st.acc[m][rr];
     } else {
-      u32x2 w;
+      const int r = wid + rr * NF;
+      d0 = NM * (4 * g + r);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
-      *reinterpret_cast<u32x2*>(dst) = w;
-    }
-  } else {
-    const int64_t slot = ((int64_t)b * H + head) * splits + split;
-    float* dst = part_o + slot * D + d0;
+      for (int m = 0; m < NM; ++m) {
+        float v = 0.f;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) dst[m] = o[m];
-    if (g == 0 && wid == 0) {
-      part_ml[slot * 2] = M;
-      part_ml[slot * 2 + 1] = L;
+        for (int w = 0; w < NW; ++w) v += s_acc[w][m * 4 + r][lane] * f[w];
+        o[m] = v;
+      }
     }
+    if (splits == 1) {
+      uint16_t* dst = out + (int64_t)b * out_stride + (int64_t)head * D + d0;
+      if constexpr (NM == 8) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+        *reinterpret_cast<u32x4*>(dst) = w;
+      } else {
+        u32x2 w;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+        *reinterpret_cast<u32x2*>(dst) = w;
+      }
+    } else {
+      float* dst = part_o + slot * D + d0;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) dst[m] = o[m];
+    }
+  }
+  if (splits > 1 && g == 0 && wid == 0) {
+    part_ml[slot * 2] = M;
+    part_ml[slot * 2 + 1] = L;
   }
 }
 
@@ -946,16 +965,26 @@ __global__ __launch_bounds__(256, 2) void prefill_lds_kernel(
 }
 
 // ------------------------------------------------------------------ C ABI
-// Wavefronts per workgroup: 8 (two per SIMD cover each other's waits; D=128 holds two chunks of K/V in ~200 VGPRs).
-// NV_ATTN_WAVES (4, 8, or 16 at D=64) selects another instantiation; read on every call so one process can
+// Wavefronts per workgroup, from the number of (sequence, kv head, split) groups of the launch.  A CU holds 8
+// wavefronts of this kernel (two per SIMD), so smaller workgroups put several groups on a CU: one group's dependent
+// start (context length -> block table -> first K/V rows) and its merge then overlap the others' streaming, and each
+// wavefront walks more chunks with its loads running ahead.  About a thousand wavefronts in total keep the memory
+// system busy; beyond that, fewer per group win.  Measured (us per launch with 8 / 4 / 2 / 1 wavefronts):
+//   128 seqs x 8 kv heads of 128, context 180:   30.0 / 23.9 / 21.9 / 20.8
+//   128 seqs x 4 kv heads of 128, context 1024:  53.0 / 53.0 / 49.5 / 59.7
+//   512 seqs x 4 kv heads of 128, context 1024:  199.7 / 198.8 / 197.6 / 193.1
+//   128 seqs x 2 kv heads of 64,  context 1024:  15.8 / 15.6 / 16.2 / -
+// The choice depends on the launch shape only, never on the context lengths, so a captured launch stays valid for
+// every replay.  Never 1 by itself: a long straggler of a ragged batch would stream at a single wavefront's rate.
+// NV_ATTN_WAVES (1, 2, 4, 8, or 16 at D=64) selects another instantiation; read on every call so one process can
 // compare them.
-static int decode_waves(int D) {
+static int decode_waves(int D, int64_t groups) {
   if (const char* e = getenv("NV_ATTN_WAVES")) {
     const int forced = atoi(e);
-    if (forced == 4 || forced == 8) return forced;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     if (forced == 16) return D == 128 ? 8 : 16;
   }
-  return 8;
+  return groups > 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
@@ -1001,7 +1030,7 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
   const float scale2 = scale * LOG2E;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
-  const int nw = decode_waves(D);
+  const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits);
   dim3 grid(num_splits, Hkv, B);
 #define LAUNCH_DEC(TT, DD, WW)                                                                                       \
   paged_decode_kernel<TT, DD, WW><<<grid, dim3(WW * 64), 0, s>>>(                                                    \
@@ -1009,7 +1038,14 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
       context_lens, (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv, block_size, scale2, num_splits)
 #define LAUNCH_DEC_T(TT)                                                         \
   do {                                                                           \
-    if (D == 128) { if (nw == 4) LAUNCH_DEC(TT, 128, 4); else LAUNCH_DEC(TT, 128, 8); } \
+    if (D == 128) {                                                              \
+      if (nw == 1) LAUNCH_DEC(TT, 128, 1);                                       \
+      else if (nw == 2) LAUNCH_DEC(TT, 128, 2);                                  \
+      else if (nw == 4) LAUNCH_DEC(TT, 128, 4);                                  \
+      else LAUNCH_DEC(TT, 128, 8);                                               \
+    }                                                                            \
+    else if (nw == 1) LAUNCH_DEC(TT, 64, 1);                                     \
+    else if (nw == 2) LAUNCH_DEC(TT, 64, 2);                                     \
     else if (nw == 4) LAUNCH_DEC(TT, 64, 4);                                     \
     else if (nw == 8) LAUNCH_DEC(TT, 64, 8);                                     \
     else LAUNCH_DEC(TT, 64, 16);                                                 \

@@ -66,6 +66,10 @@ if __name__ == "__main__":
         run(128, 28, 4, 128, S, 8, [1])
     elif which == "7b":
         run(128, 28, 4, 128, S, 8, [1, 2])
+    elif which == "qwen3":    # Qwen3-0.6B geometry at the short contexts of the reference's own bench script
+        run(128, 16, 8, 128, S, 28, [1])
+    elif which == "7b512":
+        run(512, 28, 4, 128, S, 4, [1])
     elif which == "prefill":
         run_prefill(8, 1024, 14, 2, 64)
         run_prefill(2, 4096, 14, 2, 64)

@@ -184,12 +184,12 @@ def test_paged_decode_attention(name, cfg, splits):
     OA.check_close(got, want, want_abs, f"paged decode splits={splits}")
 
 
-@pytest.mark.parametrize("waves", ["4", "8", "16"])
-@pytest.mark.parametrize("cfg", [PAGED_CASES[0], PAGED_CASES[5], PAGED_CASES[6], PAGED_CASES[7]])
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
+@pytest.mark.parametrize("cfg", [PAGED_CASES[0], PAGED_CASES[2], PAGED_CASES[5], PAGED_CASES[6], PAGED_CASES[7]])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_paged_decode_forced_wavefront_counts(cfg, waves, splits, monkeypatch):
-    """Every compiled workgroup size of the decode kernel (4, 8, 16 wavefronts; 16 exists at D=64 only and falls
-    back to 8 at D=128) is the same function."""
+    """Every compiled workgroup size of the decode kernel (1, 2, 4, 8, 16 wavefronts; 16 exists at D=64 only and
+    falls back to 8 at D=128) is the same function.  Without the override the launch shape picks among 2, 4 and 8."""
     from byox_vllm_amd import kernels
     monkeypatch.setenv("NV_ATTN_WAVES", waves)
     q, kc, vc, ctx, tables = _paged_case(dt=torch.bfloat16, **cfg)
@@ -229,7 +229,7 @@ def test_paged_decode_single_chunk_mutation(D, H, Hkv, n, splits):
 @pytest.mark.parametrize("D,H,Hkv", [(64, 14, 2), (128, 28, 4)])
 @pytest.mark.parametrize("n", [1024, 1999, 3000])
 @pytest.mark.parametrize("splits", [1, 2, 5])
-@pytest.mark.parametrize("waves", ["4", "8", "16"])
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 def test_paged_decode_chunk_census(D, H, Hkv, n, splits, waves, monkeypatch):
     """V marks every 32-key chunk with its own output dimension (V[token, d] = 1 iff d == chunk % D), so O[d] is the
     softmax mass of the chunks mapped to d: a chunk that is skipped, read twice or read from the wrong rows shows up
