@@ -52,7 +52,9 @@ _PROTOS = {
     "nv_allreduce": (_i, [_p, _p, _p, _i, _p, _i64, _i, _i, _p]),
     "nv_allreduce_add_rmsnorm": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i64, _i, _f, _i, _p]),
     "nv_embed": (_i, [_p, _p, _p, _i64, _i, _i64, _i64, _i, _p]),
-    "nv_sample_workspace_bytes": (_sz, [_i]),
+    "nv_sample_workspace_bytes": (_sz, [_i, _i]),
+    "nv_lm_head_sample_workspace_bytes": (_sz, [_i64, _i]),
+    "nv_lm_head_sample": (_i, [_p, _i64, _p, _i, _p, _i64, _p, _p, _p, _sz, _i64, _i, _i, _u64, _p, _i, _p]),
     "nv_sample": (_i, [_p, _i64, _p, _p, _p, _p, _sz, _i, _i, _u64, _p, _i, _p]),
     "nv_stage_decode_packed": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "nv_stage_decode_packed_advance": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),

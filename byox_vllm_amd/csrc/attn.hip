@@ -975,15 +975,17 @@ __global__ __launch_bounds__(256, 2) void prefill_lds_kernel(
 //   512 seqs x 4 kv heads of 128, context 1024:  199.7 / 198.8 / 197.6 / 193.1
 //   128 seqs x 2 kv heads of 64,  context 1024:  15.8 / 15.6 / 16.2 / -
 // The choice depends on the launch shape only, never on the context lengths, so a captured launch stays valid for
-// every replay.  Never 1 by itself: a long straggler of a ragged batch would stream at a single wavefront's rate.
+// every replay.  One wavefront per group only where the block table cannot describe more than 512 tokens per
+// sequence: a long straggler of a ragged batch would otherwise stream at a single wavefront's rate.
 // NV_ATTN_WAVES (1, 2, 4, 8, or 16 at D=64) selects another instantiation; read on every call so one process can
 // compare them.
-static int decode_waves(int D, int64_t groups) {
+static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
   if (const char* e = getenv("NV_ATTN_WAVES")) {
     const int forced = atoi(e);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     if (forced == 16) return D == 128 ? 8 : 16;
   }
+  if (groups > 512 && max_tokens <= 512) return 1;
   return groups > 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
@@ -1030,7 +1032,7 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
   const float scale2 = scale * LOG2E;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
-  const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits);
+  const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits, (int64_t)bt_stride * block_size);
   dim3 grid(num_splits, Hkv, B);
 #define LAUNCH_DEC(TT, DD, WW)                                                                                       \
   paged_decode_kernel<TT, DD, WW><<<grid, dim3(WW * 64), 0, s>>>(                                                    \

@@ -64,6 +64,35 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float 
   return (uint32_t)f32_to_bits<T>(lo) | ((uint32_t)f32_to_bits<T>(hi) << 16);
 }
 
+// The four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48) exchanged on the VALU: v_permlane16_swap and
+// v_permlane32_swap trade rows / halves between two registers without the LDS crossbar a __shfl_xor goes through.
+// With both operands holding x, rows_pair16 returns (value of the even row, value of the odd row) of the lane's row
+// pair, rows_pair32 (value of the lower half, value of the upper half) at the lane's position: the same two numbers in
+// the same order in both lanes of a pair, so a reduction over them gives every lane identical bits.
+typedef uint32_t u32x2_swap __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rows_pair16(uint32_t x, uint32_t& even, uint32_t& odd) {
+  const u32x2_swap r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  even = r[0];
+  odd = r[1];
+}
+__device__ __forceinline__ void rows_pair32(uint32_t x, uint32_t& lower, uint32_t& upper) {
+  const u32x2_swap r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  lower = r[0];
+  upper = r[1];
+}
+__device__ __forceinline__ void rows_pair16(float x, float& even, float& odd) {
+  uint32_t a, b;
+  rows_pair16(__float_as_uint(x), a, b);
+  even = __uint_as_float(a);
+  odd = __uint_as_float(b);
+}
+__device__ __forceinline__ void rows_pair32(float x, float& lower, float& upper) {
+  uint32_t a, b;
+  rows_pair32(__float_as_uint(x), a, b);
+  lower = __uint_as_float(a);
+  upper = __uint_as_float(b);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -28,11 +28,13 @@
 #define GEMM_BK 128
 
 #include "rope_common.h"
+#include "sample_parts.h"
 
 struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
+  SampleParts stats;   // epi == 4 only
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
@@ -149,6 +151,7 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   NV_CHECK_ARG(mtiles <= 65535 && split_k <= 65535, "nv_gemm: M=%lld too large for one launch", (long long)M);
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.rope = RopeArgs{};
+  a.stats = SampleParts{};
   a.stream = (hipStream_t)stream;
   // Where the planner wants 128 rows x 192 columns per workgroup of int4 weights, the 32x32x16 kernel covers the same
   // tile with its conversion work hidden under the MFMAs (gemm_wide.h); NV_GEMM_WIDE=1 / 0 forces it on (where the
@@ -171,6 +174,55 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   return NV_OK;
 }
 
+
+// ---- LM head + sampler: logits = x . W^T (stored, the caller may read them), one token per row.  The GEMM's epilogue
+// leaves the sampler's per-part statistics in the workspace, so the sampler's pass over the stored logits (a read of
+// rows x vocabulary x 2 bytes and a launch) is not needed; the draw is the one nv_sample makes from the same logits,
+// bit for bit (same statistics, same stage 2).
+int nv_sample_pick_launch(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* tokens,
+                          void* workspace, int B, int V, uint64_t seed, const uint64_t* seed_offset, int dtype,
+                          hipStream_t s);
+
+extern "C" size_t nv_lm_head_sample_workspace_bytes(int64_t M, int V) { return sample_parts_bytes(M, V); }
+
+extern "C" int nv_lm_head_sample(const void* x, int64_t x_row_stride, const void* w, int wfmt, void* logits,
+                                 int64_t logits_row_stride, const float* temperatures, int64_t* tokens,
+                                 void* workspace, size_t workspace_bytes, int64_t M, int V, int K, uint64_t seed,
+                                 const uint64_t* seed_offset, int dtype, nv_stream_t stream) {
+  NV_CHECK_ARG(x && w && logits && temperatures && tokens, "nv_lm_head_sample: null pointer");
+  NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_lm_head_sample: bad dtype %d", dtype);
+  NV_CHECK_ARG(unquantised(wfmt), "nv_lm_head_sample: weight format %d (the vocabulary matrix is never quantised)", wfmt);
+  NV_CHECK_ARG(V > 0 && V % 16 == 0 && V <= NV_SAMPLE_MAX_VOCAB, "nv_lm_head_sample: V=%d must be a multiple of 16, at most %d", V, NV_SAMPLE_MAX_VOCAB);
+  NV_CHECK_ARG(K > 0 && K % GEMM_BK == 0, "nv_lm_head_sample: K=%d must be a multiple of %d", K, GEMM_BK);
+  NV_CHECK_ARG(x_row_stride % 8 == 0 && logits_row_stride % 4 == 0 && logits_row_stride >= V, "nv_lm_head_sample: bad row strides");
+  NV_CHECK_ARG(((uintptr_t)x | (uintptr_t)w) % 16 == 0 && (uintptr_t)logits % 8 == 0, "nv_lm_head_sample: misaligned pointer");
+  NV_CHECK_ARG(M >= 0 && M <= 65535, "nv_lm_head_sample: M=%lld", (long long)M);
+  if (M == 0) return NV_OK;
+  const size_t need = sample_parts_bytes(M, V);
+  NV_CHECK_ARG(workspace && workspace_bytes >= need && (uintptr_t)workspace % 4 == 0,
+               "nv_lm_head_sample: workspace %zu bytes < %zu needed", workspace_bytes, need);
+  GemmArgs a;
+  a.x = x; a.xs = x_row_stride; a.w = w; a.scales = nullptr; a.bias = nullptr; a.out = logits; a.os = logits_row_stride;
+  a.partial = nullptr; a.M = M; a.N = V; a.K = K; a.split_k = 1; a.wfmt = wfmt;
+  a.ntw = pick_ntw(M, V, K, wfmt, 1, false);
+  if (const char* e = getenv("NV_GEMM_NTW")) {   // measurement aid
+    const int v = atoi(e);
+    if (v >= 1 && v <= 2) a.ntw = v;
+  }
+  a.bm = plan_rows(M, K, a.ntw, 1);
+  a.epi = 4;
+  a.rope = RopeArgs{};
+  a.wide = 0;
+  a.stats.P = (V + SAMPLE_PART_COLS - 1) / SAMPLE_PART_COLS;
+  a.stats.m = (float*)workspace;
+  a.stats.s = a.stats.m + M * a.stats.P;
+  a.stats.temps = temperatures;
+  a.stream = (hipStream_t)stream;
+  if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
+  NV_CHECK_LAUNCH();
+  return nv_sample_pick_launch(logits, logits_row_stride, temperatures, tokens, workspace, (int)M, V, seed, seed_offset,
+                               dtype, (hipStream_t)stream);
+}
 
 // Rows per workgroup for the one-launch q/k/v projection (a workgroup = one head over all of K, so the grid is
 // heads x row tiles) and its estimated duration, with the same per-K-block figures as plan_cost.
@@ -234,6 +286,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   if (M == 0) return NV_OK;
   GemmArgs a;
   a.wide = 0;
+  a.stats = SampleParts{};
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
   a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;
   a.bm = rope_fused_plan(M, K, wfmt, H + 2 * Hkv, D, nullptr);

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "rope_common.h"
+#include "sample_parts.h"
 
 #define GEMM_BK 128
 
@@ -55,11 +56,12 @@ __device__ __forceinline__ typename VecOf<T>::x8 dequant_w8(uint32_t lo, uint32_
 // dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
 template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
+                                                            //      4 = store + the sampler's per-part statistics (LM head)
 __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                    const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
                                                    int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
-                                                   int K, int split_k, RopeArgs ra) {
+                                                   int K, int split_k, RopeArgs ra, SampleParts sp) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int TM = BM / 16;                       // 16-row tiles of x per workgroup
   constexpr int XCH = BM * 16;                      // 16-byte chunks in one x tile
@@ -316,6 +318,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
     }
   }
   STAMP(st_t2);
+  // the rows' sampling temperatures: asked for here so that the loads land during the join below
+  float c2[EPI == 4 ? TM : 1];
+  if constexpr (EPI == 4) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t m = m0 + 16 * i + c;
+      c2[i] = sp.temps[m < M ? m : M - 1];
+    }
+  }
   __syncthreads();
 
   // ---- join the two k-step groups' accumulators through LDS, half of the tiles per pass.  In the first pass
@@ -377,6 +388,71 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
       const f32x4 x2 = *reinterpret_cast<const f32x4*>(src + DD / 2 + 4 * sub);
       const int64_t t = live ? m0 + r : 0;
       rope_finish<T>(x1, x2, ra, (int)blockIdx.x, t, sub, out + t * out_stride + (int64_t)blockIdx.x * DD, true, live);
+    }
+    return;
+  }
+
+  // ---- logits + sampler statistics: the store of EPI 0, and for every row the (maximum, mass) of each 64-column
+  // part (sample_parts.h), formed from the values as stored.  A part is the four tiles of column-group wavefronts:
+  // tile (wid, j) of this workgroup is slot wid * NTW + j; tile statistics meet in LDS and one thread per (row, part)
+  // joins them.
+  if constexpr (EPI == 4) {
+    constexpr int SLOTS = 4 * NTW;
+    float* st_m = reinterpret_cast<float*>(lds_raw);     // [BM][SLOTS]; the reduction's last reads are behind a barrier
+    float* st_s = st_m + BM * SLOTS;
+    float* st_c = st_s + BM * SLOTS;                     // [BM] log2(e) / T of each row, for the join below
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      c2[i] = sample_exp_scale(c2[i]);
+      if (wave == 0 && g == 0) st_c[16 * i + c] = c2[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int nt = nt0 + j;
+      const bool tile_live = nt < ntiles;
+      const int nb = 16 * (tile_live ? nt : ntiles - 1) + 4 * g;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(bias + nb);
+        b4[0] = lo_f32<T>(t[0]); b4[1] = hi_f32<T>(t[0]); b4[2] = lo_f32<T>(t[1]); b4[3] = hi_f32<T>(t[1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!owns(j * TM + i)) continue;                  // wave-uniform
+        const int64_t m = m0 + 16 * i + c;
+        u32x2 o;
+        o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
+        o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
+        if (m < M && tile_live) *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+        float v[4] = {lo_f32<T>(o[0]), hi_f32<T>(o[0]), lo_f32<T>(o[1]), hi_f32<T>(o[1])};
+        if (!tile_live) v[0] = v[1] = v[2] = v[3] = -INFINITY;
+        float tm, ts;
+        sample_tile16(v, c2[i], tm, ts);
+        if (g == 0) {
+          const int slot = (16 * i + c) * SLOTS + wid * NTW + j;
+          st_m[slot] = tm;
+          st_s[slot] = ts;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int PARTS = NTW;                            // 64-column parts per workgroup
+    for (int item = tid; item < BM * PARTS; item += 512) {
+      const int r = item / PARTS, q = item - r * PARTS;
+      const int64_t m = m0 + r;
+      const int part = blockIdx.x * PARTS + q;
+      if (m >= M || part >= sp.P) continue;
+      float tm[4], ts[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        tm[t] = st_m[r * SLOTS + 4 * q + t];
+        ts[t] = st_s[r * SLOTS + 4 * q + t];
+      }
+      float pm, psum;
+      sample_join4(tm, ts, st_c[r], pm, psum);
+      const int64_t o = m * sp.P + part;
+      sp.m[o] = pm;
+      sp.s[o] = psum;
     }
     return;
   }
@@ -475,6 +551,7 @@ struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
+  SampleParts stats;   // epi == 4 only
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 #endif
@@ -484,7 +561,7 @@ static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 #define GO(BMV)                                                                                               \
   gemm_kernel<T, WFMT, BMV, NTW, EPI><<<grid, dim3(512), 0, a.stream>>>(                                      \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,  \
-      a.os, a.partial, a.M, a.N, a.K, a.split_k, a.rope)
+      a.os, a.partial, a.M, a.N, a.K, a.split_k, a.rope, a.stats)
   switch (a.bm) {
     case 16: GO(16); break;
     case 32: GO(32); break;
@@ -499,6 +576,9 @@ static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
   if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
   else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
   else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
+  else if (a.epi == 4) {   // the LM head is never quantised
+    if constexpr (WFMT == NV_W_DENSE || WFMT == NV_W_DENSE_TILED) gemm_go_bm<T, WFMT, NTW, 4>(a, grid);
+  }
   else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3>(a, grid);   // a head is 64 or 128 columns
 }
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "common.h"
+#include "sample_parts.h"
 
 static thread_local char g_err[512] = "";
 void nv_set_error(const char* fmt, ...) {
@@ -209,223 +210,260 @@ __global__ __launch_bounds__(256) void sample_final_kernel(const float* __restri
 // ---- sampling without injected noise: inverse CDF --------------------------------------------------------------
 // Drawing a token from softmax(l / T) by the Gumbel / exponential-noise argmax costs a hash and two logarithms per
 // logit (VALU-bound: 30 us for 128 x 152k logits).  With the noise drawn in-kernel anyway, the same distribution comes
-// cheaper from the inverse CDF with ONE uniform per row: stage 1 (grid (splits, B)) gives every slice its maximum m_k
-// (also the greedy candidate) and s_k = sum exp((l - m_k) / T); stage 2 (one workgroup per row) picks the slice by
-// the weights s_k exp((m_k - M) / T), then walks that slice's prefix sums to the token.  One exp per logit.
-template <typename T>
-__device__ __forceinline__ void load8(const uint16_t* __restrict__ row, int i, int V, bool vec_ok, float (&x)[8]) {
-  if (vec_ok) {
-    const u32x4 t = reinterpret_cast<const u32x4*>(row)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      x[2 * j] = lo_f32<T>(t[j]);
-      x[2 * j + 1] = hi_f32<T>(t[j]);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (8 * i + j < V) ? bits_to_f32<T>(row[8 * i + j]) : -INFINITY;
-  }
-}
+// cheaper from the inverse CDF with ONE uniform per row: stage 1 describes every 64-column part of the row by its
+// maximum m_k (also the greedy candidate) and its mass s_k = sum exp((l - m_k) / T) (sample_parts.h; the LM-head GEMM
+// can deliver the same arrays from its epilogue, then stage 1 is not launched at all); stage 2 (one wavefront per
+// row) picks the part by the weights s_k exp((m_k - M) / T), then the column inside it.  One exp per logit.
 
 // 2^x by the hardware instruction alone (arguments here are <= 0 and results only feed sums: no denormal care)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__device__ __forceinline__ float block_sum_256(float v, float* s_red) {   // 256 threads, result in every thread
-  v = wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+// Stage 1 over stored logits.  A wavefront takes 256 columns (four parts) of one row at a time: lane (c, g) holds
+// columns 16 c + 4 g .. + 3 of them, which is the register layout the GEMM epilogue has.  The four tiles of a part sit
+// in four neighbouring lanes (a quad), so the join reads them with quad broadcasts.  Eight such groups are loaded
+// before the first is reduced; groups past the row's end are loaded from the last group and not stored.
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), Q * 0x55, 0xf, 0xf, false));
 }
 
-#define SAMPLE_QUARTERS 4   // wavefronts per slice: each owns a contiguous quarter and reports its own mass
-
+#define SAMPLE_SCAN_DEPTH 8
 template <typename T>
-__global__ __launch_bounds__(256) void sample_cdf_scan_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
-                                                              const float* __restrict__ temps, float* __restrict__ pv,
-                                                              int* __restrict__ pi, float* __restrict__ ps, int V) {
-  __shared__ float s_val[4];
-  __shared__ int s_idx[4];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+__global__ __launch_bounds__(256) void sample_parts_scan_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                                SampleParts sp, int V) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wid = threadIdx.x >> 6;
   const uint16_t* row = logits + (int64_t)b * row_stride;
-  const float temp = temps[b];
-  const bool vec_ok = (V % 8 == 0) && (row_stride % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
-  const int nvec = (V + 7) >> 3;
-  const int per = (nvec + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
-  const int v0 = blockIdx.x * per;
-  const int v1 = v0 + per < nvec ? v0 + per : nvec;
-  const int quarter = (per + SAMPLE_QUARTERS - 1) / SAMPLE_QUARTERS;
-  const int q0 = v0 + wid * quarter, q1 = (q0 + quarter < v1) ? q0 + quarter : v1;
-  // one pass: every thread keeps its best (value, index) and, for sampled rows, the sum of exp((x - best) / T)
-  // relative to its own running maximum (rescaled when the maximum moves)
-  const bool sampled = temp != 0.0f;
-  const float c = sampled ? LOG2E_F / temp : 0.f;
-  Best best = {-INFINITY, 0x7fffffff};
-  float sum = 0.f;
-  for (int i = q0 + lane; i < q1; i += 64) {
-    float x[8];
-    load8<T>(row, i, V, vec_ok, x);
-    Best vb = {x[0], 8 * i};
+  const float c2 = sample_exp_scale(sp.temps[b]);
+  const bool vec_ok = (row_stride % 4 == 0) && (((uintptr_t)logits) % 8 == 0);
+  const int groups = (sp.P + 3) >> 2;                                // 256-column groups in the row
+  // wavefront w of workgroup x takes groups (4 x + w) * DEPTH .. + DEPTH - 1, then the same 4 * gridDim.x * DEPTH further
+  for (int g0 = (blockIdx.x * 4 + wid) * SAMPLE_SCAN_DEPTH; g0 < groups; g0 += 4 * gridDim.x * SAMPLE_SCAN_DEPTH) {
+    float v[SAMPLE_SCAN_DEPTH][4];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) vb = better(vb, Best{x[j], 8 * i + j});
-    if (sampled && vb.v > -INFINITY) {
-      const float m_new = fmaxf(best.v, vb.v);
-      float add = 0.f;
+    for (int u = 0; u < SAMPLE_SCAN_DEPTH; ++u) {
+      const int gi = min(g0 + u, groups - 1);
+      const int col = 256 * gi + 16 * c + 4 * g;
+      if (vec_ok && col + 4 <= V) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(row + col);
+        v[u][0] = lo_f32<T>(t[0]); v[u][1] = hi_f32<T>(t[0]); v[u][2] = lo_f32<T>(t[1]); v[u][3] = hi_f32<T>(t[1]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) add += fast_exp2((x[j] - m_new) * c);
-      sum = sum * fast_exp2((best.v - m_new) * c) + add;   // best.v == -inf: sum is 0 and the factor exp2(-inf) = 0
+        for (int e = 0; e < 4; ++e) v[u][e] = (col + e < V) ? bits_to_f32<T>(row[col + e]) : -INFINITY;
+      }
     }
-    best = better(best, vb);
-  }
-  const float my_max = best.v;
-  best = wave_best(best);
-  if (lane == 0) {
-    s_val[wid] = best.v;
-    s_idx[wid] = best.i;
-  }
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) best = better(best, Best{s_val[w], s_idx[w]});   // the slice's best, in every thread
-  if (sampled && my_max > -INFINITY) sum *= fast_exp2((my_max - best.v) * c);
-  else sum = 0.f;
-  sum = wave_sum(sum);                     // this quarter's mass relative to the slice maximum
-  const int slice = b * SAMPLE_SPLITS + blockIdx.x;
-  if (lane == 0) ps[slice * SAMPLE_QUARTERS + wid] = sum;
-  if (tid == 0) {
-    pv[slice] = best.v;
-    pi[slice] = best.i;
+#pragma unroll
+    for (int u = 0; u < SAMPLE_SCAN_DEPTH; ++u) {
+      float tm_own, ts_own;
+      sample_tile16(v[u], c2, tm_own, ts_own);
+      const float tm[4] = {quad_bcast<0>(tm_own), quad_bcast<1>(tm_own), quad_bcast<2>(tm_own), quad_bcast<3>(tm_own)};
+      const float m = sample_join_max(tm);
+      const float w_own = sample_join_weight(tm_own, ts_own, m, c2);      // this lane's tile; the quad holds all four
+      const float w[4] = {quad_bcast<0>(w_own), quad_bcast<1>(w_own), quad_bcast<2>(w_own), quad_bcast<3>(w_own)};
+      const float s = sample_join_sum(w);
+      const int part = 4 * (g0 + u) + (c >> 2);
+      if (g == 0 && (c & 3) == 0 && part < sp.P) {
+        const int64_t o = (int64_t)b * sp.P + part;
+        sp.m[o] = m;
+        sp.s[o] = s;
+      }
+    }
   }
 }
 
-// One wavefront per row: choose (slice, quarter) by the reported masses, then walk that quarter 64 vectors at a time
-// (lane l takes vector base + l: coalesced; four batches of loads in flight) with a prefix scan over the lanes.
+// Stage 2: one workgroup of four wavefronts per row.  The row's part maxima and masses go to LDS with coalesced
+// loads (all in flight at once); thread t then owns the contiguous run of parts [t per, (t + 1) per): the runs'
+// masses, a scan over the threads for the run that holds the target, and - on the first wavefront alone - a scan over
+// that run's parts and one over the 64 columns of the chosen part (one column per lane).  A greedy row goes straight
+// to the columns of the first part that holds the row's maximum.
 template <typename T>
-__global__ __launch_bounds__(64) void sample_cdf_pick_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
-                                                             const float* __restrict__ temps,
-                                                             const float* __restrict__ pv, const int* __restrict__ pi,
-                                                             const float* __restrict__ ps, int64_t* __restrict__ tokens,
-                                                             int V, uint64_t seed,
-                                                             const uint64_t* __restrict__ seed_offset) {
-  constexpr int NP = SAMPLE_SPLITS * SAMPLE_QUARTERS;   // 32 parts per row: one lane each
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float temp = temps[b];
-  const int part_k = (lane < NP ? lane : NP - 1) / SAMPLE_QUARTERS;
-  const float m_part = pv[b * SAMPLE_SPLITS + part_k];
-  const int i_part = pi[b * SAMPLE_SPLITS + part_k];
-  const float s_part = lane < NP ? ps[b * NP + lane] : 0.f;
-  const Best top = wave_best(Best{m_part, i_part});
-  if (temp == 0.0f || !(top.v > -INFINITY)) {   // greedy (or a row without a finite logit)
-    if (lane == 0) tokens[b] = top.i;
+__global__ __launch_bounds__(256) void sample_parts_pick_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                                SampleParts sp, int64_t* __restrict__ tokens, int V,
+                                                                uint64_t seed, const uint64_t* __restrict__ seed_offset) {
+  extern __shared__ float pick_lds[];            // [P] maxima, [P] weights
+  __shared__ float s_top_v[4], s_total[4], s_below;
+  __shared__ int s_top_i[4];
+  __shared__ unsigned long long s_reach[4], s_any[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, P = sp.P;
+  const float temp = sp.temps[b];
+  const float* pm = sp.m + (int64_t)b * P;
+  const float* ps = sp.s + (int64_t)b * P;
+  const uint16_t* row = logits + (int64_t)b * row_stride;
+  float* lm = pick_lds;
+  float* lw = pick_lds + P;
+  Best top = {-INFINITY, 0x7fffffff};            // (maximum, part): parts are in column order, so the lowest part wins ties
+#pragma unroll 4
+  for (int k = tid; k < P; k += 256) {
+    const float m = pm[k];
+    lm[k] = m;
+    lw[k] = ps[k];
+    top = better(top, Best{m, k});
+  }
+  top = wave_best(top);
+  if (lane == 0) {
+    s_top_v[wid] = top.v;
+    s_top_i[wid] = top.i;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) top = better(top, Best{s_top_v[w], s_top_i[w]});
+  // the column of a part's maximum: the first of its 64 logits that equals it
+  auto column_of_max = [&](int part, float m) {
+    const int col = part * SAMPLE_PART_COLS + lane;
+    const float x = col < V ? bits_to_f32<T>(row[col]) : -INFINITY;
+    const unsigned long long hit = __ballot(x == m);
+    return hit ? part * SAMPLE_PART_COLS + __ffsll((long long)hit) - 1 : 0;
+  };
+  if (temp == 0.0f || !(top.v > -INFINITY)) {    // greedy (or a row without a finite logit)
+    if (wid == 0) {
+      const int tok = top.i < P ? column_of_max(top.i, top.v) : 0;
+      if (lane == 0) tokens[b] = tok;
+    }
     return;
   }
-  const float c = LOG2E_F / temp;
+  const float c2 = SAMPLE_LOG2E / temp;
   if (seed_offset) seed += seed_offset[0] * 0x9e3779b97f4a7c15ull;   // per-replay stream inside a captured graph
   const uint64_t key = mix64(seed ^ ((uint64_t)b << 32));
   const float u = ((float)(uint32_t)(key >> 40) + 0.5f) * (1.0f / 16777216.0f);   // uniform in (0, 1)
-  const float weight = s_part > 0.f ? s_part * fast_exp2((m_part - top.v) * c) : 0.f;
-  float cum = weight;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float up = __shfl_up(cum, o, 64);
-    if (lane >= o) cum += up;
+  for (int k = tid; k < P; k += 256) {           // masses relative to the row maximum (a thread's own writes: no barrier)
+    const float s = lw[k];
+    lw[k] = s > 0.f ? s * fast_exp2((lm[k] - top.v) * c2) : 0.f;
   }
-  const float target = u * __shfl(cum, 63, 64);
-  // the first part with mass whose running total reaches the target; rounding may leave none: take the last with mass
-  const unsigned long long reach = __ballot(weight > 0.f && cum >= target);
-  const unsigned long long any = __ballot(weight > 0.f);
-  const int sel = reach ? __ffsll((long long)reach) - 1 : 63 - __clzll((long long)any);
-  const float m_sel = __shfl(m_part, sel, 64);
-  const float resid = (target - (__shfl(cum, sel, 64) - __shfl(weight, sel, 64))) / fast_exp2((m_sel - top.v) * c);
-  int token = __shfl(i_part, sel, 64);          // fall-back: the selected slice's best token
-
-  const uint16_t* row = logits + (int64_t)b * row_stride;
-  const bool vec_ok = (V % 8 == 0) && (row_stride % 8 == 0) && (((uintptr_t)logits) % 16 == 0);
-  const int nvec = (V + 7) >> 3;
-  const int per = (nvec + SAMPLE_SPLITS - 1) / SAMPLE_SPLITS;
-  const int quarter = (per + SAMPLE_QUARTERS - 1) / SAMPLE_QUARTERS;
-  const int v0 = (sel / SAMPLE_QUARTERS) * per;
-  const int v1 = v0 + per < nvec ? v0 + per : nvec;
-  const int q0 = v0 + (sel % SAMPLE_QUARTERS) * quarter, q1 = (q0 + quarter < v1) ? q0 + quarter : v1;
-  float running = 0.f;
-  bool done = false;
-  for (int base = q0; base < q1 && !done; base += 256) {
-    float p[4][8];
+  __syncthreads();
+  auto scan = [&](float x) {                     // inclusive prefix sum over the lanes of a wavefront
 #pragma unroll
-    for (int u4 = 0; u4 < 4; ++u4) {               // four batches of loads in flight
-      const int i = base + 64 * u4 + lane;
-      float x[8];
-      if (i < q1) load8<T>(row, i, V, vec_ok, x);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) p[u4][j] = (i < q1) ? fast_exp2((x[j] - m_sel) * c) : 0.f;
+    for (int o = 1; o < 64; o <<= 1) {
+      const float up = __shfl_up(x, o, 64);
+      if (lane >= o) x += up;
     }
+    return x;
+  };
+  // the first lane with mass whose running total reaches the target; rounding may leave none: the last with mass
+  auto choose = [&](float w, float incl, float target) {
+    const unsigned long long reach = __ballot(w > 0.f && incl >= target);
+    const unsigned long long any = __ballot(w > 0.f);
+    return reach ? __ffsll((long long)reach) - 1 : (any ? 63 - __clzll((long long)any) : 0);
+  };
+  const int per = (P + 255) >> 8;
+  const int k0 = min(P, tid * per), k1 = min(P, k0 + per);
+  float run = 0.f;
+  for (int k = k0; k < k1; ++k) run += lw[k];
+  float run_incl = scan(run);
+  if (lane == 63) s_total[wid] = run_incl;
+  __syncthreads();
+  float before = 0.f, grand = 0.f;
 #pragma unroll
-    for (int u4 = 0; u4 < 4; ++u4) {
-      if (done) break;
-      const int i = base + 64 * u4 + lane;
-      float part = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part += p[u4][j];
-      float incl = part;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const float up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-      }
-      const float excl = running + incl - part;
-      const bool mine = part > 0.f && excl < resid && resid <= running + incl;
-      if (mine) {
-        float acc = excl;
-        int pick = -1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          acc += p[u4][j];
-          if (pick < 0 && p[u4][j] > 0.f && acc >= resid) pick = 8 * i + j;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)                 // rounding: the last token of the vector that carries mass
-          if (pick < 0 && p[u4][7 - j] > 0.f) pick = 8 * i + 7 - j;
-        token = pick;
-      }
-      const unsigned long long found = __ballot(mine);
-      if (found) {
-        token = __shfl(token, __ffsll((long long)found) - 1, 64);
-        done = true;
-      }
-      running += __shfl(incl, 63, 64);
+  for (int w = 0; w < 4; ++w) {
+    if (w < wid) before += s_total[w];
+    grand += s_total[w];
+  }
+  run_incl += before;
+  const float target = u * grand;
+  {
+    const unsigned long long reach = __ballot(run > 0.f && run_incl >= target);
+    const unsigned long long any = __ballot(run > 0.f);
+    if (lane == 0) {
+      s_reach[wid] = reach;
+      s_any[wid] = any;
     }
   }
+  __syncthreads();
+  int sel_thread = -1, last_mass = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (sel_thread < 0 && s_reach[w]) sel_thread = 64 * w + __ffsll((long long)s_reach[w]) - 1;
+    if (s_any[w]) last_mass = 64 * w + 63 - __clzll((long long)s_any[w]);
+  }
+  if (sel_thread < 0) sel_thread = last_mass;
+  if (tid == sel_thread) s_below = run_incl - run;   // mass before the chosen run
+  __syncthreads();
+  if (wid != 0) return;
+  float below = s_below;
+  // the part inside the run, 64 parts at a time
+  const int r0 = min(P, sel_thread * per), r1 = min(P, r0 + per);
+  int part = r0 < P ? r0 : P - 1;
+  float part_below = below;
+  for (int base = r0; base < r1; base += 64) {
+    const int k = base + lane;
+    const float w = k < r1 ? lw[k] : 0.f;
+    const float incl = scan(w);
+    const float total = __shfl(incl, 63, 64);
+    const bool last = base + 64 >= r1;
+    if (below + total >= target || last) {
+      const int sel = choose(w, below + incl, target);
+      part = base + sel;
+      part_below = below + __shfl(incl, sel, 64) - __shfl(w, sel, 64);
+      break;
+    }
+    below += total;
+  }
+  // the column inside the part: masses relative to the part's own maximum
+  const float m_part = lm[part];
+  const float resid = (target - part_below) / fast_exp2((m_part - top.v) * c2);
+  const int col = part * SAMPLE_PART_COLS + lane;
+  const float x = col < V ? bits_to_f32<T>(row[col]) : -INFINITY;
+  const float p = x > -INFINITY ? fast_exp2((x - m_part) * c2) : 0.f;
+  const float p_incl = scan(p);
+  const int sel_col = choose(p, p_incl, resid);
+  int token = part * SAMPLE_PART_COLS + sel_col;
+  if (!__ballot(p > 0.f) || token >= V) token = column_of_max(top.i, top.v);   // cannot happen for a part with mass
   if (lane == 0) tokens[b] = token;
 }
 
-extern "C" size_t nv_sample_workspace_bytes(int B) { return (size_t)B * SAMPLE_SPLITS * (8 + 4 * SAMPLE_QUARTERS); }
+extern "C" size_t nv_sample_workspace_bytes(int B, int V) {
+  const size_t noise_path = (size_t)B * SAMPLE_SPLITS * 8, parts = sample_parts_bytes(B, V);
+  return noise_path > parts ? noise_path : parts;
+}
+
+// Views of a workspace of sample_parts_bytes(B, V) bytes.
+static SampleParts sample_parts_of(void* workspace, int64_t B, int V, const float* temperatures) {
+  SampleParts sp;
+  sp.P = (V + SAMPLE_PART_COLS - 1) / SAMPLE_PART_COLS;
+  sp.m = (float*)workspace;
+  sp.s = sp.m + B * sp.P;
+  sp.temps = temperatures;
+  return sp;
+}
+
+// Stage 2 alone: the statistics are already in the workspace (written by the LM-head GEMM's epilogue).
+int nv_sample_pick_launch(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* tokens,
+                          void* workspace, int B, int V, uint64_t seed, const uint64_t* seed_offset, int dtype,
+                          hipStream_t s) {
+  const SampleParts sp = sample_parts_of(workspace, B, V, temperatures);
+  const size_t lds = (size_t)sp.P * 8;         // nv_sample / nv_lm_head_sample bound V so that this fits
+  if (dtype == NV_BF16)
+    sample_parts_pick_kernel<bf16_t><<<dim3(B), dim3(256), lds, s>>>((const uint16_t*)logits, logits_row_stride, sp, tokens, V, seed, seed_offset);
+  else
+    sample_parts_pick_kernel<f16_t><<<dim3(B), dim3(256), lds, s>>>((const uint16_t*)logits, logits_row_stride, sp, tokens, V, seed, seed_offset);
+  NV_CHECK_LAUNCH();
+  return NV_OK;
+}
 
 extern "C" int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
                          int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
                          const uint64_t* seed_offset, int dtype, nv_stream_t stream) {
   NV_CHECK_ARG(logits && temperatures && tokens, "nv_sample: null pointer");
   NV_CHECK_ARG(dtype == NV_BF16 || dtype == NV_F16, "nv_sample: bad dtype %d", dtype);
-  NV_CHECK_ARG(V > 0 && B >= 0 && B <= 65535, "nv_sample: bad shape B=%d V=%d", B, V);
+  NV_CHECK_ARG(V > 0 && V <= NV_SAMPLE_MAX_VOCAB && B >= 0 && B <= 65535, "nv_sample: bad shape B=%d V=%d", B, V);
   if (B == 0) return NV_OK;
-  NV_CHECK_ARG(workspace && workspace_bytes >= nv_sample_workspace_bytes(B) && (uintptr_t)workspace % 4 == 0,
-               "nv_sample: workspace %zu bytes < %zu needed", workspace_bytes, nv_sample_workspace_bytes(B));
+  NV_CHECK_ARG(workspace && workspace_bytes >= nv_sample_workspace_bytes(B, V) && (uintptr_t)workspace % 4 == 0,
+               "nv_sample: workspace %zu bytes < %zu needed", workspace_bytes, nv_sample_workspace_bytes(B, V));
   hipStream_t s = (hipStream_t)stream;
   float* pv = (float*)workspace;
   int* pi = (int*)(pv + (size_t)B * SAMPLE_SPLITS);
   dim3 grid(SAMPLE_SPLITS, B);
-  if (!noise) {   // greedy rows and in-kernel randomness: maxima + partition sums, then one inverse-CDF draw per row
-    float* ps = (float*)(pi + (size_t)B * SAMPLE_SPLITS);
-    if (dtype == NV_BF16) {
-      sample_cdf_scan_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, pv, pi, ps, V);
-      NV_CHECK_LAUNCH();
-      sample_cdf_pick_kernel<bf16_t><<<dim3(B), dim3(64), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
-                                                                   pv, pi, ps, tokens, V, seed, seed_offset);
-    } else {
-      sample_cdf_scan_kernel<f16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures, pv, pi, ps, V);
-      NV_CHECK_LAUNCH();
-      sample_cdf_pick_kernel<f16_t><<<dim3(B), dim3(64), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,
-                                                                  pv, pi, ps, tokens, V, seed, seed_offset);
-    }
+  if (!noise) {   // greedy rows and in-kernel randomness: part maxima + masses, then one inverse-CDF draw per row
+    const SampleParts sp = sample_parts_of(workspace, B, V, temperatures);
+    const int groups = (sp.P + 3) / 4;
+    int slices = (groups + 4 * SAMPLE_SCAN_DEPTH - 1) / (4 * SAMPLE_SCAN_DEPTH);   // one round of loads per wavefront
+    while (slices > 1 && (int64_t)slices * B > 4096) slices = (slices + 1) / 2;     // unless that floods the chip
+    if (slices < 1) slices = 1;
+    if (dtype == NV_BF16)
+      sample_parts_scan_kernel<bf16_t><<<dim3(slices, B), dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, sp, V);
+    else
+      sample_parts_scan_kernel<f16_t><<<dim3(slices, B), dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, sp, V);
     NV_CHECK_LAUNCH();
-    return NV_OK;
+    return nv_sample_pick_launch(logits, logits_row_stride, temperatures, tokens, workspace, B, V, seed, seed_offset,
+                                 dtype, s);
   }
   if (dtype == NV_BF16)
     sample_partial_kernel<bf16_t><<<grid, dim3(256), 0, s>>>((const uint16_t*)logits, logits_row_stride, temperatures,

@@ -444,6 +444,7 @@ class ModelRunner:
         # Config.graph_head = False) it holds the forward only; logits gather and sampling follow outside, as in the
         # reference (model_runner.py:253-254).
         self.graph_has_head = self.world_size == 1 and self.config.graph_head and not self.single_rank_rccl
+        self.fused_head_sampler = os.environ.get("NV_FUSED_HEAD_SAMPLER", "1") != "0"   # 0: measurement aid
         self.graph_bs = sorted(config.graph_batch_sizes) if config.graph_batch_sizes else graph_batch_sizes(max_bs)
         max_bs = self.graph_bs[-1]
         self.max_graph_bs = max_bs
@@ -462,9 +463,13 @@ class ModelRunner:
             if not self.graph_has_head:
                 g["outputs"][:bs] = hidden        # the caller computes logits outside the graph (TP gather)
             else:                                 # head and sampler inside the graph: no copy of the hidden states
-                logits = self.model.compute_logits(hidden)
-                kernels.sample(logits, g["temperatures"][:bs], seed=self.config.seed, seed_offset=g["step"],
-                               out=g["tokens"][:bs])
+                if self.fused_head_sampler:       # the LM head's epilogue feeds the sampler: one pass over the logits less
+                    self.model.sample_tokens(hidden, g["temperatures"][:bs], self.config.seed, seed_offset=g["step"],
+                                             out=g["tokens"][:bs])
+                else:
+                    logits = self.model.compute_logits(hidden)
+                    kernels.sample(logits, g["temperatures"][:bs], seed=self.config.seed, seed_offset=g["step"],
+                                   out=g["tokens"][:bs])
                 # the graph ends by delivering the tokens to pinned host memory: the host then only waits for the stream
                 self._host_tokens[:bs].copy_(g["tokens"][:bs], non_blocking=True)
 

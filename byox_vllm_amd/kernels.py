@@ -278,11 +278,35 @@ def sample(logits, temperatures, noise=None, seed=0, out=None, seed_offset=None)
     if noise is not None:
         assert noise.dtype == torch.float32 and noise.shape == logits.shape and noise.is_contiguous()
     out = torch.empty(B, dtype=torch.int64, device=logits.device) if out is None else out
-    ws = workspace(lib().nv_sample_workspace_bytes(B), logits.device, "sample")
+    ws = workspace(lib().nv_sample_workspace_bytes(B, V), logits.device, "sample")
     check(lib().nv_sample(ptr(logits), logits.stride(0), ptr(temperatures), ptr(noise), ptr(out), ptr(ws), ws.numel(),
                           B, V, seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_offset), dtype_code(logits.dtype), stream()),
           "nv_sample")
     return out
+
+
+def lm_head_sample(x, w, temperatures, seed=0, out=None, seed_offset=None, logits=None):
+    """LM head and sampler chained (embed_head.py:54-66 + sampler.py:11-15 of the reference): x [M, K] against the
+    vocabulary matrix ``w`` (an unquantised LinearWeight) -> (tokens [M], logits [M, V]).  The GEMM's epilogue hands
+    the sampler its statistics, so the logits are not read again; the tokens are those of ``sample(gemm(x, w), ...)``
+    bit for bit, which is also what runs where the GEMM planner would split K (small vocabularies)."""
+    require_gpu(x, "lm_head_sample")
+    M, K = x.shape
+    V = w.out_features
+    assert K == w.in_features and x.stride(1) == 1 and x.dtype == w.dtype and w.scales is None
+    assert temperatures.dtype == torch.float32 and temperatures.numel() == M
+    out = torch.empty(M, dtype=torch.int64, device=x.device) if out is None else out
+    logits = torch.empty(M, V, dtype=x.dtype, device=x.device) if logits is None else logits
+    assert logits.shape == (M, V) and logits.stride(1) == 1
+    if V % 16 or pick_split_k(M, V, K, w.fmt) != 1:
+        gemm(x, w, out=logits)
+        return sample(logits, temperatures, seed=seed, out=out, seed_offset=seed_offset), logits
+    ws = workspace(lib().nv_lm_head_sample_workspace_bytes(M, V), x.device, "sample")
+    check(lib().nv_lm_head_sample(ptr(x), x.stride(0), ptr(w.data), w.fmt, ptr(logits), logits.stride(0),
+                                  ptr(temperatures), ptr(out), ptr(ws), ws.numel(), M, V, K,
+                                  seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_offset), dtype_code(x.dtype), stream()),
+          "nv_lm_head_sample")
+    return out, logits
 
 
 def stage_decode_inputs(ids, positions, slots, context_lens, block_tables, g):

@@ -64,6 +64,18 @@ class ParallelLMHead(VocabParallelEmbedding):
         if self.weight is not None and packed.data.data_ptr() != self.weight.data_ptr():
             self.weight = None
 
+    def forward_sample(self, x: torch.Tensor, temperatures: torch.Tensor, seed: int, seed_offset=None, out=None):
+        """``forward`` chained with the sampler on one rank (sampler.py:11-15 after embed_head.py:54-66): -> (tokens,
+        logits).  The sampler's statistics come out of the GEMM's epilogue; the tokens are those ``Sampler`` draws from
+        ``forward``'s logits with the same seed."""
+        assert not collectives_on(self.tp_size), "the fused head + sampler is a single-rank path"
+        context = get_context()
+        if context.is_prefill:
+            last = (context.cu_seqlens_q[1:] - 1).long()
+            x = x[last].contiguous()
+        return kernels.lm_head_sample(x, self._streaming_weight(), temperatures, seed=seed, seed_offset=seed_offset,
+                                      out=out)
+
     def forward(self, x: torch.Tensor):
         context = get_context()
         if context.is_prefill:

@@ -173,6 +173,13 @@ class Qwen3ForCausalLM(nn.Module):
     def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
         return self.lm_head(hidden_states)
 
+    def sample_tokens(self, hidden_states: torch.Tensor, temperatures: torch.Tensor, seed: int, seed_offset=None,
+                      out=None) -> torch.Tensor:
+        """compute_logits followed by the sampler, single rank (the step's tail, model_runner.py:253-254 and :62 of the
+        reference): the tokens ``Sampler`` would draw from ``compute_logits(hidden_states)`` with this seed."""
+        tokens, _ = self.lm_head.forward_sample(hidden_states, temperatures, seed, seed_offset=seed_offset, out=out)
+        return tokens
+
     def finalize(self, quantization: str | None = None) -> None:
         """Convert every layer linear to its kernel-side weight (the LM head and embedding stay dense)."""
         from byox_vllm_amd.layers.linear import LinearBase

@@ -196,12 +196,24 @@ int nv_embed(const int64_t* ids, const void* weight, void* out, int64_t T, int h
  * to the lowest index.  logits are in `dtype` (NV_BF16/NV_F16) rows of V.
  * Without `noise` the draw uses the inverse CDF of softmax(logits/T) with one uniform per row from (seed, b):
  * the same distribution as the noisy argmax at one exp per logit instead of a hash and two logs. */
-size_t nv_sample_workspace_bytes(int B);
+size_t nv_sample_workspace_bytes(int B, int V);
 int nv_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, const float* noise,
               int64_t* tokens, void* workspace, size_t workspace_bytes, int B, int V, uint64_t seed,
               const uint64_t* seed_offset /* device word mixed into the seed, or NULL: lets a captured
                                              launch draw fresh noise on every replay */,
               int dtype, nv_stream_t stream);
+
+/* ParallelLMHead.forward + Sampler.forward in two launches — nanovllm/layers/embed_head.py:54-66 (decode branch,
+ * one rank) followed by sampler.py:11-15, as the decode step chains them (engine/model_runner.py:253-254, 62).
+ * logits[M, V] = x[M, K] . w[V, K]^T are stored in `dtype` as nv_gemm stores them; the GEMM's epilogue also leaves,
+ * per row and 64-column part, the maximum, the lowest column holding it and the softmax mass at the row's
+ * temperature, from which tokens[m] is drawn exactly as nv_sample (noise == NULL) draws it from the stored logits:
+ * same token bit for bit, without nv_sample's pass over the logits.  w: NV_W_DENSE or NV_W_DENSE_TILED. */
+size_t nv_lm_head_sample_workspace_bytes(int64_t M, int V);
+int nv_lm_head_sample(const void* x, int64_t x_row_stride, const void* w, int wfmt, void* logits,
+                      int64_t logits_row_stride, const float* temperatures, int64_t* tokens, void* workspace,
+                      size_t workspace_bytes, int64_t M, int V, int K, uint64_t seed, const uint64_t* seed_offset,
+                      int dtype, nv_stream_t stream);
 
 /* Graph-replay staging — nanovllm/engine/model_runner.py:246-252 as ONE launch:
  * copies the step's ids/positions/slots/context_lens/block_tables into the

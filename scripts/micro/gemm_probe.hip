@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
   auto launch = [&](int c) {
     gemm_kernel<bf16_t, PROBE_WFMT, PROBE_BM, PROBE_NTW, PROBE_EPI><<<grid, dim3(512)>>>(
         (const uint16_t*)dx, K, dw[c], (const uint16_t*)ds[c], nullptr, (uint16_t*)dout, PROBE_EPI == 1 ? N / 2 : N,
-        dpart, M, N, K, split, RopeArgs{});
+        dpart, M, N, K, split, RopeArgs{}, SampleParts{});
   };
 #endif
   for (int c = 0; c < copies; ++c) launch(c);

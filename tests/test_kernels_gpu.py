@@ -702,6 +702,68 @@ def test_sampler_in_kernel_randomness_follows_softmax(V, temp):
     assert (toks2[::2] == 3).all() and (toks2[1::2] != toks[1::2]).any()
 
 
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("M,V,K,ntw", [(1, 4096, 256, "1"), (5, 4112, 128, "2"), (16, 20000, 256, "1"), (33, 8208, 384, "2"),
+                                       (128, 151936, 128, "2"), (200, 30000 - 30000 % 16, 256, "1")])
+def test_lm_head_sample_equals_gemm_then_sample(name, M, V, K, ntw, monkeypatch):
+    """The chained LM head + sampler (statistics from the GEMM's epilogue) stores the logits nv_gemm stores and draws
+    the tokens nv_sample draws from them, bit for bit: greedy rows, sampled rows at several temperatures, vocabularies
+    that end inside a 64-column part, both tile widths, tiled and row-major weights."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    monkeypatch.setenv("NV_GEMM_NTW", ntw)
+    dt = DT[name]
+    g = torch.Generator().manual_seed(M * 7 + V)
+    x = dev(torch.randn(M, K, generator=g).to(dt))
+    w = dev((torch.randn(V, K, generator=g) * 0.3).to(dt))
+    temps = torch.tensor([0.0, 0.6, 1.0, 1.7])[torch.arange(M) % 4].float()
+    for packed in (LinearWeight.dense_tiled(w) if K % 128 == 0 else LinearWeight.dense(w), LinearWeight.dense(w)):
+        want_logits = kernels.gemm(x, packed, split_k=1)
+        want = kernels.sample(want_logits, dev(temps), seed=99)
+        lib_call = kernels.lib().nv_lm_head_sample
+        ws = kernels.workspace(kernels.lib().nv_lm_head_sample_workspace_bytes(M, V), x.device, "sample")
+        ws.zero_()
+        tokens = torch.empty(M, dtype=torch.int64, device=x.device)
+        logits = torch.empty(M, V, dtype=dt, device=x.device)
+        kernels.check(lib_call(kernels.ptr(x), x.stride(0), kernels.ptr(packed.data), packed.fmt, kernels.ptr(logits),
+                               logits.stride(0), kernels.ptr(dev(temps)), kernels.ptr(tokens), kernels.ptr(ws),
+                               ws.numel(), M, V, K, 99, None, kernels.dtype_code(dt), kernels.stream()),
+                      "nv_lm_head_sample")
+        assert torch.equal(logits, want_logits)
+        assert tokens.cpu().tolist() == want.cpu().tolist()
+        greedy = temps == 0
+        assert tokens.cpu()[greedy].tolist() == want_logits.float().argmax(-1).cpu()[greedy].tolist()
+        assert len(set(tokens.cpu()[~greedy].tolist())) > 1 or M < 3
+        # the python wrapper takes the same route (or gemm + sample where the planner splits K)
+        got, got_logits = kernels.lm_head_sample(x, packed, dev(temps), seed=99)
+        assert torch.equal(got_logits, kernels.gemm(x, packed)) or kernels.pick_split_k(M, V, K, packed.fmt) == 1
+        if kernels.pick_split_k(M, V, K, packed.fmt) == 1:
+            assert got.cpu().tolist() == want.cpu().tolist()
+
+
+def test_lm_head_sample_follows_softmax():
+    """Rows of one hidden state against a vocabulary matrix with a few strong columns: the fused draw comes out at
+    the softmax rates of the stored logits."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    V, K, B = 20000, 128, 512
+    idx = [5, 2600, 9000, 15555, V - 1]
+    w = torch.zeros(V, K)
+    w[:, 0] = -30.0
+    w[idx, 0] = torch.tensor([1.0, 0.5, 0.0, -0.5, 0.8])
+    x = torch.zeros(B, K)
+    x[:, 0] = 1.0
+    packed = LinearWeight.dense_tiled(dev(w.to(torch.bfloat16)))
+    counts = np.zeros(len(idx))
+    for seed in range(8):
+        toks, logits = kernels.lm_head_sample(dev(x.to(torch.bfloat16)), packed, dev(torch.full((B,), 0.8)), seed=seed)
+        toks = toks.cpu().numpy()
+        assert set(toks.tolist()) <= set(idx)
+        counts += np.array([(toks == i).sum() for i in idx])
+    want = torch.softmax(logits[0].float().cpu() / 0.8, dim=-1)[idx].numpy()
+    assert np.abs(counts / counts.sum() - want).max() < 0.03, (counts / counts.sum(), want)
+
+
 def test_stage_decode_inputs_pads_like_reference():
     from byox_vllm_amd import kernels
     bs, padded, cols, gcols = 3, 8, 2, 5
