@@ -30,11 +30,14 @@
 #include "rope_common.h"
 #include "sample_parts.h"
 
+#define GEMM_MIXED_TILES 10   /* 16-column tiles per workgroup of gemm_mixed_kernel (gemm_impl.h) */
+
 struct GemmArgs {
   const void* x; int64_t xs; const void* w; const void* scales; const void* bias; void* out; int64_t os;
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
   SampleParts stats;   // epi == 4 only
+  int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
@@ -161,6 +164,23 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
     a.wide = a.ntw == 3 && a.bm == 128;
     if (const char* e = getenv("NV_GEMM_WIDE")) a.wide = atoi(e) == 1;   // measurement aid
   }
+  // Where three tiles per wavefront were chosen and the launch is a single, partly filled round of workgroups,
+  // 160-column workgroups (gemm_mixed_kernel) fill more CUs with shorter workgroups: Qwen2-7B gate_up at 128 rows
+  // 48.0 us in 237 workgroups against 53.1 / 53.7 us in 198 (32x32x16 / 16x16x32 kernel).  Over several rounds
+  // (512 rows: 948 against 792 workgroups) the extra x tile traffic of the additional workgroups loses: 182 against
+  // 174 us.  NV_GEMM_MIXED=1 / 0 forces it.
+  a.mixed = 0;
+  if (!unquantised(wfmt) && M > 64 && a.ntw == 3 && a.bm == 128) {
+    const int64_t mt = (M + 127) / 128, ntl = N / 16;
+    const int64_t blocks_mixed = (ntl + GEMM_MIXED_TILES - 1) / GEMM_MIXED_TILES * mt * split_k;
+    const int64_t blocks_three = (ntl + 11) / 12 * mt * split_k;
+    a.mixed = blocks_mixed <= 256 && blocks_mixed > blocks_three;
+  }
+  if (const char* e = getenv("NV_GEMM_MIXED")) {   // measurement aid
+    a.mixed = atoi(e) == 1 && !unquantised(wfmt) && M > 64;
+    if (a.mixed) a.bm = 128;
+  }
+  if (a.mixed) a.wide = 0;
   if (a.wide) {
     if (dtype == NV_BF16) nv_gemm_wide_launch_bf16(a); else nv_gemm_wide_launch_f16(a);
   } else {
@@ -213,6 +233,7 @@ extern "C" int nv_lm_head_sample(const void* x, int64_t x_row_stride, const void
   a.epi = 4;
   a.rope = RopeArgs{};
   a.wide = 0;
+  a.mixed = 0;
   a.stats.P = (V + SAMPLE_PART_COLS - 1) / SAMPLE_PART_COLS;
   a.stats.m = (float*)workspace;
   a.stats.s = a.stats.m + M * a.stats.P;
@@ -286,6 +307,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   if (M == 0) return NV_OK;
   GemmArgs a;
   a.wide = 0;
+  a.mixed = 0;
   a.stats = SampleParts{};
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
   a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;

@@ -54,29 +54,37 @@ __device__ __forceinline__ typename VecOf<T>::x8 dequant_w8(uint32_t lo, uint32_
 // A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
 // two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
 // dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
+// LDS of one workgroup: the double-buffered x tile, reused for the k-group join and the epilogues' staging.
+template <int BM, int NTW, int EPI>
+constexpr int gemm_lds_bytes() {
+  constexpr int TM = BM / 16, RED_REGS = (NTW * TM + 1) / 2;
+  constexpr int LDS_X = 2 * BM * GEMM_BK * 2, LDS_RED = RED_REGS * 256 * 16;
+  constexpr int LDS_STAGE = (EPI == 3) ? BM * (64 * NTW + 4) * 4 : 0;   // fp32 rows of one head, padded against conflicts
+  constexpr int LDS_XR = LDS_X > LDS_RED ? LDS_X : LDS_RED;
+  return LDS_XR > LDS_STAGE ? LDS_XR : LDS_STAGE;
+}
+
+// The work of one wavefront of a 512-thread workgroup: column group `wid` (0..3) of k-step group `kg` (0..1), NTW
+// tiles starting at tile nt0.  The caller owns the LDS block and decides which wavefront is which; all wavefronts of
+// a workgroup must run the same BM and EPI (they meet at the same barriers) but may differ in NTW.
 template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
                                                             //      4 = store + the sampler's per-part statistics (LM head)
-__global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
-                                                   const void* __restrict__ w, const uint16_t* __restrict__ scales,
-                                                   const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
-                                                   int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
-                                                   int K, int split_k, RopeArgs ra, SampleParts sp) {
+__device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_t x_stride,
+                                          const void* __restrict__ w, const uint16_t* __restrict__ scales,
+                                          const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                          int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
+                                          int K, int split_k, const RopeArgs& ra, const SampleParts& sp,
+                                          uint8_t* lds_raw, int wid, int kg, int nt0) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int TM = BM / 16;                       // 16-row tiles of x per workgroup
   constexpr int XCH = BM * 16;                      // 16-byte chunks in one x tile
   constexpr int XV = (XCH + 511) / 512;             // chunks per thread
   constexpr int RED_REGS = (NTW * TM + 1) / 2;      // accumulator tiles exchanged per reduction pass
-  constexpr int LDS_X = 2 * BM * GEMM_BK * 2, LDS_RED = RED_REGS * 256 * 16;
-  constexpr int LDS_STAGE = (EPI == 3) ? BM * (64 * NTW + 4) * 4 : 0;   // fp32 rows of one head, padded against conflicts
-  constexpr int LDS_XR = LDS_X > LDS_RED ? LDS_X : LDS_RED;
-  constexpr int LDS_BYTES = LDS_XR > LDS_STAGE ? LDS_XR : LDS_STAGE;
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES];
   uint16_t (*lds_x)[BM * GEMM_BK] = reinterpret_cast<uint16_t (*)[BM * GEMM_BK]>(lds_raw);
 
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wid = wave & 3, kg = wave >> 2;         // column group of 4 wavefronts, k-step group
   const int64_t m0 = (int64_t)blockIdx.y * BM;
   const int nkb_total = K / GEMM_BK;
   const int per = (nkb_total + split_k - 1) / split_k;   // K-blocks of this split: contiguous range
@@ -84,7 +92,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   int kb_end = kb_begin + per;
   if (kb_end > nkb_total) kb_end = nkb_total;
   const int ntiles = N >> 4;
-  const int nt0 = (blockIdx.x * 4 + wid) * NTW;          // this wavefront's first 16-column tile
 
   STAMP_DECL;
   f32x4 acc[NTW][TM];
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   // place: there group 0 takes both halves).  a + b == b + a bit for bit, so the owner does not change the result.
   {
     f32x4* red = reinterpret_cast<f32x4*>(lds_raw);   // [RED_REGS][256 threads of the column group]
-    const int t4 = tid & 255;
+    const int t4 = wid * 64 + lane;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int giver = (EPI == 3 || pass == 0) ? 1 : 0;
@@ -520,6 +527,47 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
 #endif
 }
 
+// NTW = 16-column tiles per wavefront (a workgroup covers 64*NTW columns): the x fragment read from LDS is reused
+// for NTW MFMAs, which divides the LDS read traffic and the x re-reads from L2 by NTW.
+// A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
+// two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
+// dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
+template <typename T, int WFMT, int BM, int NTW, int EPI>
+__global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+                                                   const void* __restrict__ w, const uint16_t* __restrict__ scales,
+                                                   const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                   int64_t out_stride, float* __restrict__ partial, int64_t M, int N,
+                                                   int K, int split_k, RopeArgs ra, SampleParts sp) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[gemm_lds_bytes<BM, NTW, EPI>()];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = wave & 3, kg = wave >> 2;         // column group of 4 wavefronts, k-step group
+  gemm_body<T, WFMT, BM, NTW, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, ra, sp,
+                                   lds_raw, wid, kg, (blockIdx.x * 4 + wid) * NTW);
+}
+
+// 128 rows x 160 columns per workgroup: column groups 0 and 1 take three tiles per wavefront, groups 2 and 3 two.
+// Where N / 192 leaves a quarter of the CUs idle and N / 128 needs a second round (Qwen2-7B gate_up: 198 or 296
+// workgroups for 256 CUs), ten tiles per workgroup fill the chip in one round (237).  The second k-step group takes
+// the column groups in reverse order, so each SIMD (wavefronts w and w + 4) carries 3 + 2 tiles.
+#define GEMM_MIXED_TILES 10
+template <typename T, int WFMT, int EPI>
+__global__ __launch_bounds__(512) void gemm_mixed_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+                                                         const void* __restrict__ w, const uint16_t* __restrict__ scales,
+                                                         const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+                                                         int64_t out_stride, float* __restrict__ partial, int64_t M,
+                                                         int N, int K, int split_k) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[gemm_lds_bytes<128, 3, EPI>()];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = wave >> 2, wid = kg ? 3 - (wave & 3) : (wave & 3);
+  const int first = blockIdx.x * GEMM_MIXED_TILES;
+  if (wid < 2)
+    gemm_body<T, WFMT, 128, 3, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
+                                    SampleParts{}, lds_raw, wid, kg, first + 3 * wid);
+  else
+    gemm_body<T, WFMT, 128, 2, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
+                                    SampleParts{}, lds_raw, wid, kg, first + 6 + 2 * (wid - 2));
+}
+
 // Sum the split-K slabs in slab order, add the bias, round to the model dtype.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
@@ -552,6 +600,7 @@ struct GemmArgs {
   float* partial; int64_t M; int N; int K; int split_k; int wfmt; int bm; int ntw; int epi; hipStream_t stream;
   RopeArgs rope;   // epi == 3 only
   SampleParts stats;   // epi == 4 only
+  int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
 };
 #endif
@@ -582,9 +631,25 @@ static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
   else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3>(a, grid);   // a head is 64 or 128 columns
 }
 
+template <typename T, int WFMT>
+static void gemm_go_mixed(const GemmArgs& a) {
+  const int ntiles = a.N / 16;
+  dim3 grid((ntiles + GEMM_MIXED_TILES - 1) / GEMM_MIXED_TILES, (unsigned)((a.M + 127) / 128), a.split_k);
+#define GO(EPIV)                                                                                                 \
+  gemm_mixed_kernel<T, WFMT, EPIV><<<grid, dim3(512), 0, a.stream>>>(                                            \
+      (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,     \
+      a.os, a.partial, a.M, a.N, a.K, a.split_k)
+  if (a.epi == 0) GO(0); else if (a.epi == 1) GO(1); else GO(2);
+#undef GO
+}
+
 // One dtype's instantiations: dense takes 1 or 2 tiles per wavefront (16 raw registers per tile), quantised 1 or 3.
 template <typename T>
 static void gemm_dispatch(const GemmArgs& a) {
+  if (a.mixed) {
+    if (a.wfmt == NV_W_INT8) gemm_go_mixed<T, NV_W_INT8>(a); else gemm_go_mixed<T, NV_W_INT4>(a);
+    return;
+  }
   const int ntiles = a.N / 16;
   const int per_block = 4 * a.ntw;
   dim3 grid((ntiles + per_block - 1) / per_block, (unsigned)((a.M + a.bm - 1) / a.bm), a.split_k);

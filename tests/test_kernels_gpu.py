@@ -495,6 +495,53 @@ def test_gemm_wide_kernel(name, M, N, K, mode, monkeypatch):
         assert (got.float() - other.float()).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
+@pytest.mark.parametrize("M,N,K", [(65, 160, 128), (128, 224, 256), (130, 480, 384), (200, 1184, 896), (128, 4608, 3584)])
+@pytest.mark.parametrize("mode", ["bias", "plain-split1", "split3", "silu"])
+def test_gemm_mixed_width_kernel(name, fmt, M, N, K, mode, monkeypatch):
+    """The 160-column workgroup (column groups of 3, 3, 2, 2 tiles, the second k-step group mirrored over the SIMDs),
+    forced on shapes with ragged rows, a last workgroup that ends inside any of its column groups, one K-block, K
+    splits, every epilogue, both quantised formats and dtypes: the same function as the uniform kernels, bit for bit
+    (the same k-steps are summed in the same order), and within 1 ulp of the fp64 product."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    if name == "fp16" and K > 1024:
+        pytest.skip("long-K shapes are checked in bf16 (an fp32 sum over 3584 terms against one fp16 ulp near zero)")
+    dt = DT[name]
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    w_ref = Q.dequantize_w4(*Q.quantize_w4(w)) if fmt == "w4a16" else Q.dequantize_w8(*Q.quantize_w8(w))
+
+    def both(fn):
+        monkeypatch.setenv("NV_GEMM_MIXED", "1")
+        got = fn()
+        monkeypatch.setenv("NV_GEMM_MIXED", "0")
+        monkeypatch.setenv("NV_GEMM_WIDE", "0")
+        return got, fn()
+
+    if mode == "silu":
+        if N % 32:
+            pytest.skip("gate and up halves need N / 2 to be a multiple of 16")
+        lw = LinearWeight.make(interleave_gate_up(dev(w)), fmt)
+        got, other = both(lambda: kernels.gemm(dev(x), lw, silu_mul=True))
+        assert torch.equal(got, other)
+        # against the oracle's chain of three roundings (gate and up to the model dtype, silu, product): a gate that
+        # the fp32 accumulation rounds to the neighbouring value moves silu by one ulp and the product by up to three
+        ulp_close(got, L.silu_and_mul(L.linear(x, w_ref)), name, ulps=3.0)
+        return
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt) if mode == "bias" else None
+    split = {"bias": 1, "plain-split1": 1, "split3": 3}[mode]
+    if split > K // 128:
+        pytest.skip("fewer K-blocks than splits")
+    want = torch.nn.functional.linear(x.double(), w_ref.double(), None if bias is None else bias.double())
+    lw = LinearWeight.make(dev(w), fmt)
+    got, other = both(lambda: kernels.gemm(dev(x), lw, None if bias is None else dev(bias), split_k=split))
+    ulp_close(got, want.to(dt), name, ulps=1.0)
+    assert torch.equal(got, other)
+
+
 def _linear_fp64_rounded(x, w_ref, bias=None, rows=16384):
     """F.linear in fp64 on the CPU, rounded once to the model dtype; W is walked in row slices to bound memory."""
     xd = x.double()
