@@ -18,6 +18,10 @@ python3 $R/scripts/pmc_table.py $O/pmc_write paged_decode >> $O/pmc_attn.txt
 python3 $R/scripts/pmc_table.py $O/pmc_gemm1 gemm_ > $O/pmc_gemm.txt
 python3 $R/scripts/pmc_table.py $O/pmc_gemm2 gemm_ >> $O/pmc_gemm.txt
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_gemm1 $O/pmc_gemm2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kref -o b -- python3 $R/bench.py --no-cpu-baseline --workload ref-bench --steps 2 --warmup 1 > $O/bench_ref_under_rocprof.json 2>/dev/null || exit 1
+rm -f $O/kref/*kernel_trace.csv
+for w in 1 2 4 8; do NV_ATTN_WAVES=$w timeout -k 10 100 python3 $R/scripts/bench_attn.py qwen3 180 2>/dev/null; NV_ATTN_WAVES=$w timeout -k 10 100 python3 $R/scripts/bench_attn.py 7b 2>/dev/null | grep "splits=1"; NV_ATTN_WAVES=$w timeout -k 10 100 python3 $R/scripts/bench_attn.py pmc 1024 2>/dev/null; done > $O/attn_waves.txt
+timeout -k 10 100 python3 $R/scripts/bench_head.py > $O/head_sampler.txt 2>/dev/null
 timeout -k 10 200 python3 $R/scripts/bench_attn.py prefill > $O/prefill_attn.txt 2>/dev/null
 timeout -k 10 200 python3 $R/scripts/bench_gemm.py 7b 128 > $O/gemm_7b.txt 2>/dev/null
 timeout -k 10 200 python3 $R/scripts/bench_gemm.py 0.5b 128 > $O/gemm_05b.txt 2>/dev/null
