@@ -101,7 +101,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """The current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Python
+    Stream object on every call (about 8 us, once per launch); the raw getter is a plain C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -277,6 +277,11 @@ extern "C" int nv_gemm_rope_kv_store_is_faster(int64_t M, int K, int wfmt, int H
       const double us = plan_cost(M, N, K, wfmt, ntw, s, s > 1);
       if (us < split) split = us;
     }
+  // Over many rounds of workgroups the RoPE epilogue (a head's rows staged through LDS, then walked row by row)
+  // costs more than a plain store plus the memory-bound RoPE kernel.  Measured, one launch against two: Qwen3-0.6B
+  // bf16 at 14.6 k rows 311 us against ~225 (prefill 562 k -> 600 k tok/s), Qwen2-0.5B int4 at 32 k rows 2 % slower,
+  // equal at 8 k rows, 10 % FASTER at 2 k rows; Qwen2-7B int4 at 512 rows 0.4 % faster.
+  if (M > 4096) return 0;
   return fused < split + 4.5 ? 1 : 0;   // + the stand-alone RoPE / cache-store launch
 }
 

@@ -76,6 +76,7 @@ class ModelRunner:
         torch.cuda.set_device(local)
         self.device = torch.device("cuda", local)
         default_dtype = torch.get_default_dtype()
+        default_device = torch.get_default_device()
         torch.set_default_dtype(hf_config.dtype)
         torch.set_default_device(self.device)
         try:
@@ -94,7 +95,11 @@ class ModelRunner:
             if not self.enforce_eager:
                 self._capture_graphs()
         finally:
-            torch.set_default_device("cpu")
+            # Back to the caller's default.  Where that is the CPU the device context is REMOVED rather than set to
+            # "cpu" (the reference sets "cpu", model_runner.py:47): an installed context routes every later torch call
+            # - each tensor.data_ptr() and .stride() of the launch wrappers included - through a Python
+            # __torch_function__ hook, about 3,400 calls and several milliseconds per eager prefill step.
+            torch.set_default_device(None if default_device.type == "cpu" else default_device)
             torch.set_default_dtype(default_dtype)
 
         if self.world_size > 1 and event is not None:

@@ -20,7 +20,7 @@ _retired: list[torch.Tensor] = []   # outgrown buffers stay alive: captured grap
 def workspace(nbytes: int, device, tag: str = "main") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag).  Size it before graph capture."""
     # one buffer per stream: micro-batches captured on parallel streams must not share scratch space
-    key = (torch.device(device).index or 0, tag, torch.cuda.current_stream().cuda_stream)
+    key = (device.index if isinstance(device, torch.device) else torch.device(device).index, tag, stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:

@@ -68,6 +68,11 @@ if __name__ == "__main__":
         run(128, 28, 4, 128, S, 8, [1, 2])
     elif which == "qwen3":    # Qwen3-0.6B geometry at the short contexts of the reference's own bench script
         run(128, 16, 8, 128, S, 28, [1])
+    elif which == "batches":  # split choice at the smaller graph batch sizes (combine launch included)
+        for B in (8, 16, 32, 64):
+            run(B, 14, 2, 64, S, 24, [1, 2, 4, 8, 16])
+        for B in (8, 32):
+            run(B, 28, 4, 128, S, 8, [1, 2, 4, 8])
     elif which == "7b512":
         run(512, 28, 4, 128, S, 4, [1])
     elif which == "prefill":

@@ -14,7 +14,10 @@ hf = qwen2_config(model, dtype=torch.bfloat16)
 cfg = Config("synthetic", hf_config=hf, quantization=quant, kvcache_block_size=256, num_kvcache_blocks=160,
              max_model_len=8192, max_num_seqs=64, max_num_batched_tokens=32768, enforce_eager=True)
 r = ModelRunner(cfg, 0, None)
-for nseq, length in ((1, 512), (1, 2048), (1, 8192), (8, 1024), (16, 2048)):
+shapes = ((1, 512), (1, 2048), (1, 8192), (8, 1024), (16, 2048))
+if len(sys.argv) > 3:    # e.g. "1x256,1x1024,4x1024"
+    shapes = tuple(tuple(int(v) for v in item.split("x")) for item in sys.argv[3].split(","))
+for nseq, length in shapes:
     seqs, nb = [], 0
     for _ in range(nseq):
         s = Sequence(list(range(1, length + 1)), 256)
