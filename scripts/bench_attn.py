@@ -73,6 +73,8 @@ if __name__ == "__main__":
             run(B, 14, 2, 64, S, 24, [1, 2, 4, 8, 16])
         for B in (8, 32):
             run(B, 28, 4, 128, S, 8, [1, 2, 4, 8])
+    elif which == "split2":   # the split kernel alone (read its duration from a rocprofv3 --stats run)
+        run(128, 14, 2, 64, S, 24, [2])
     elif which == "7b512":
         run(512, 28, 4, 128, S, 4, [1])
     elif which == "prefill":
