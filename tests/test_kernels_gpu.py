@@ -749,6 +749,32 @@ def test_sampler_in_kernel_randomness_follows_softmax(V, temp):
     assert (toks2[::2] == 3).all() and (toks2[1::2] != toks[1::2]).any()
 
 
+def test_sampler_masked_logits_and_limits():
+    """-inf logits (a masked vocabulary) carry no mass and are never drawn, whole parts of them included; a row with
+    a single finite logit returns it at any temperature; a vocabulary beyond the draw's LDS budget is refused."""
+    from byox_vllm_amd import kernels
+    V, B = 5000, 64
+    g = torch.Generator().manual_seed(3)
+    logits = torch.full((B, V), float("-inf"))
+    allowed = [7, 63, 64, 1000, 1001, 4095, 4999]
+    logits[:, allowed] = torch.randn(B, len(allowed), generator=g)
+    logits[0] = float("-inf")
+    logits[0, 4999] = -3.0
+    temps = torch.tensor([0.0, 0.7, 1.3, 5.0])[torch.arange(B) % 4].float()
+    lg = dev(logits.to(torch.bfloat16))
+    seen = set()
+    for seed in range(20):
+        toks = kernels.sample(lg, dev(temps), seed=seed).cpu()
+        assert set(toks.tolist()) <= set(allowed)
+        assert toks[0].item() == 4999
+        greedy = temps == 0
+        assert toks[greedy].tolist() == lg.float().argmax(-1).cpu()[greedy].tolist()
+        seen |= set(toks[~greedy].tolist())
+    assert len(seen) >= 5
+    with pytest.raises(RuntimeError, match="bad shape"):
+        kernels.sample(dev(torch.zeros(1, 64 * 8192 + 64, dtype=torch.bfloat16)), dev(torch.ones(1)))
+
+
 @pytest.mark.parametrize("name", list(DT))
 @pytest.mark.parametrize("M,V,K,ntw", [(1, 4096, 256, "1"), (5, 4112, 128, "2"), (16, 20000, 256, "1"), (33, 8208, 384, "2"),
                                        (128, 151936, 128, "2"), (200, 30000 - 30000 % 16, 256, "1")])
