@@ -64,8 +64,8 @@ class LLMEngine:
         if not seqs:
             return [], 0
         token_ids = self.model_runner.call("run", seqs, is_prefill)
-        self.scheduler.postprocess(seqs, token_ids)
-        outputs = [(seq.seq_id, seq.completion_token_ids) for seq in seqs if seq.is_finished]
+        finished = self.scheduler.postprocess(seqs, token_ids)
+        outputs = [(seq.seq_id, seq.completion_token_ids) for seq in finished]
         return outputs, (sum(len(seq) for seq in seqs) if is_prefill else -len(seqs))
 
     def _is_finished(self):

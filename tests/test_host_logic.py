@@ -357,3 +357,57 @@ def test_continues_previous_step_decision():
     seqs[2].block_table.pop()
     runner.device_bookkeeping = False
     assert runner._continues_previous_step(seqs, 4) is None
+
+
+def test_scheduler_quiet_steps_equal_the_full_pass():
+    """The scheduler's shortcut for decode steps in which nothing can change (no queue change, no sequence at a block
+    boundary) against the same scheduler walking the running queue every step (the reference's loop,
+    scheduler.py:56-91): identical batches, block tables, free lists, hashes and finish order over random workloads with
+    arrivals in mid-run, EOS, max_tokens, preemption for lack of blocks and prefix-cache hits."""
+    import random
+    from types import SimpleNamespace
+    from byox_vllm_amd.engine.scheduler import Scheduler
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+
+    def drive(quiet, seed):
+        rng = random.Random(seed)
+        Sequence.counter = __import__("itertools").count()
+        cfg = SimpleNamespace(max_num_seqs=6, max_num_batched_tokens=200, eos=3, num_kvcache_blocks=rng.choice([12, 14, 40]),
+                              kvcache_block_size=8, scheduler_quiet_steps=quiet)
+        sch = Scheduler(cfg)
+        shared = [rng.randrange(4, 50) for _ in range(16)]
+        pending = []
+        for i in range(10):
+            prompt = (shared if rng.random() < 0.4 else []) + [rng.randrange(4, 50) for _ in range(rng.randrange(1, 30))]
+            sp = SamplingParams(temperature=1.0, max_tokens=rng.randrange(1, 40), ignore_eos=rng.random() < 0.5)
+            pending.append((rng.randrange(0, 40), Sequence(prompt, 8, sp)))
+        trace, step, quiet_hits = [], 0, 0
+        while (pending or not sch.is_finished()) and step < 2000:
+            for item in [p for p in pending if p[0] <= step]:
+                sch.add(item[1])
+                pending.remove(item)
+            if sch.is_finished():
+                step += 1
+                continue
+            before = sch._quiet_left
+            seqs, is_prefill = sch.schedule()
+            quiet_hits += (not is_prefill) and before > 0
+            trace.append((is_prefill, [s.seq_id for s in seqs], [list(s.block_table) for s in seqs],
+                          list(sch.block_manager.free_block_ids), sorted(sch.block_manager.hash_to_block_id.items()),
+                          [s.seq_id for s in sch.running], [s.seq_id for s in sch.waiting]))
+            if seqs:
+                toks = [rng.choice([3, 5, 6, 7, 8, 9, 10, 11]) for _ in seqs]
+                sch.postprocess(seqs, toks)
+            step += 1
+        assert step < 2000
+        return trace, quiet_hits
+
+    total_hits = 0
+    for seed in range(25):
+        slow, hits0 = drive(False, seed)
+        fast, hits = drive(True, seed)
+        assert hits0 == 0
+        assert fast == slow, f"seed {seed}"
+        total_hits += hits
+    assert total_hits > 50          # the shortcut was actually taken
