@@ -150,11 +150,13 @@ def time_attention_kernel(runner, seqs, reps=10):
 
 
 def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0):
-    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample: a reduced batch, few steps."""
+    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample: the workload's own batch and
+    context, a few steps (a reduced batch would re-read the weights per 8 rows instead of per 128 and understate the
+    CPU); only the 7B geometry, whose setup alone takes minutes, is sampled at batch 8."""
     from byox_vllm_amd.config import qwen2_config
     from oracle import model as OM
     hf = qwen2_config(model_name, dtype=dtype)
-    sample_batch = min(batch, 8)
+    sample_batch = batch if model_name != "qwen2-7b" else min(batch, 8)
     bs = 256
     t0 = time.perf_counter()
     weights = OM.random_weights(hf, seed=0)
@@ -162,14 +164,15 @@ def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0)
         weights = OM.fake_quantize(weights, 4 if quantization == "w4a16" else 8)
     blocks_per_seq = (context + 8) // bs + 1
     om = OM.OracleQwen(hf, weights, bs, sample_batch * blocks_per_seq)
-    for kv in om.kv:
-        kv.normal_()
+    for kv in om.kv:          # random history: one block drawn, the others copies (the timing does not see values)
+        kv[:, :, :1].normal_()
+        kv[:, :, 1:] = kv[:, :, :1]
     tables = [list(range(i * blocks_per_seq, (i + 1) * blocks_per_seq)) for i in range(sample_batch)]
     lens = [context] * sample_batch
     ids = torch.randint(0, 10000, (sample_batch,))
     setup = time.perf_counter() - t0
     steps, spent = 0, 0.0
-    while steps < 1 or (spent < budget_s and steps < 4):
+    while steps < 1 or (spent < budget_s / 2 and steps < 4):
         lens = [n + 1 for n in lens]
         ctx, pos = OM.decode_ctx(lens, tables, bs)
         t1 = time.perf_counter()
@@ -354,8 +357,27 @@ def main():
             dt = t.item()
         return dt
 
-    runner, seqs, driver = build(tp)
-    elapsed = timed(driver)
+    tp_error = None
+    try:
+        if tp > 1 and os.environ.get("NV_BENCH_FAIL_TP"):      # test hook: exercises the fallback below
+            raise RuntimeError("tensor-parallel leg failed on request (NV_BENCH_FAIL_TP)")
+        runner, seqs, driver = build(tp)
+        elapsed = timed(driver)
+    except Exception as e:
+        # A tensor-parallel step that fails on this stack (on every rank alike: a rank that fails alone leaves its
+        # peers inside a collective) must not cost the whole measurement: fall back to one replica per rank, say so.
+        if tp == 1:
+            raise
+        tp_error = repr(e)
+        print(f"[bench] rank {rank}: the tensor-parallel leg failed ({tp_error}); measuring {world} replicas instead",
+              file=sys.stderr, flush=True)
+        runner = driver = None
+        torch.cuda.empty_cache()
+        from byox_vllm_amd.layers.rotary_embedding import get_rope
+        get_rope.cache_clear()
+        tp = 1
+        runner, seqs, driver = build(1)
+        elapsed = timed(driver)
 
     replicas = world // tp
     tokens = batch * args.steps * replicas
@@ -392,6 +414,7 @@ def main():
             "graph_captured": not runner.enforce_eager,
             "allreduce": (("nv_allreduce_add_rmsnorm (peer-mapped memory)" if runner.comm is not None else
                            "torch.distributed all_reduce") if tp > 1 else None),
+            "tp_error": tp_error,
             "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": bytes_step,
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ decode_combine_kernel)",

@@ -1,6 +1,6 @@
 """Do two independent kernel chains overlap when captured as two branches of one hipGraph?
 Chain = n dependent small GEMMs (0.5B o-projection shape at 64 rows).  (a) both chains one after the other on one
-stream, (b) forked onto two streams inside one capture, (c) a single chain at 128 rows (the same total work)."""
+stream, (b) forked onto two streams inside one capture, (c) a single chain at 128 rows (the same total work), (d) two graphs replayed on two streams."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -44,6 +44,27 @@ def main(n=48, K=896, N=896):
         with torch.cuda.stream(s2):
             chain(xb)
         s1.wait_stream(s2)
+    # (d) two graphs, one per chain, each replayed on its own stream
+    g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_a, stream=s1):
+        chain(xa)
+    with torch.cuda.graph(g_b, stream=s2):
+        chain(xb)
+    def both():
+        with torch.cuda.stream(s1):
+            g_a.replay()
+        with torch.cuda.stream(s2):
+            g_b.replay()
+    import time
+    both(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        both()
+    torch.cuda.synchronize()
+    two_graphs = (time.perf_counter() - t0) * 1e6 / 20
+    with torch.cuda.stream(s1):
+        one_graph = replay_us(g_a)
+    print(f"{n} GEMMs per chain: one 64-row chain as a graph {one_graph:8.1f} us | two graphs on two streams {two_graphs:8.1f} us", flush=True)
     print(f"{n} GEMMs per chain: two 64-row chains in sequence {replay_us(g_seq):8.1f} us | forked {replay_us(g_fork):8.1f} us | "
           f"one 128-row chain {replay_us(g_full):8.1f} us", flush=True)
 

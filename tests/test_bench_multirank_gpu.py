@@ -34,3 +34,20 @@ def test_bench_two_ranks(mode):
     assert d["graph_captured"] == (mode != "default")      # gloo collectives cannot be captured, the library's own can
     assert ("replicas_tok_s" in d) == (mode != "dp") and d.get("replicas_tok_s", 1) > 0
     assert "cpu_baseline" not in d                      # rank 0 times the CPU baseline at N = 1 only
+
+
+def test_bench_falls_back_to_replicas_when_the_tensor_parallel_leg_fails():
+    """A tensor-parallel step that raises on every rank must not cost the measurement: the line then reports one
+    replica per rank (weak scaling, dp2) and carries the error text."""
+    env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", NV_BENCH_FAIL_TP="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29535",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--workload", "qwen2-0.5b-fp16-b1-s128"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert "NV_BENCH_FAIL_TP" in d["tp_error"] and "replicas_tok_s" not in d
