@@ -95,3 +95,9 @@ if __name__ == "__main__":
         run(256, 7, 1, 64, 1024, 24, [1])       # same bytes, every stream contiguous
         run(128, 14, 2, 64, 4096, 6, [1])       # longer context: prologue/epilogue amortised
         run(256, 7, 1, 64, 4096, 6, [1])
+    elif which == "rows256":  # can 128 workgroups that read contiguous 256-byte rows keep up with 256 workgroups on 128-byte rows?
+        run(128, 7, 1, 128, 1100, 24, [1])      # one kv head of 128: contiguous 256-byte rows, 128 workgroups
+        run(128, 7, 1, 128, 4096, 6, [1])
+        run(128, 14, 2, 64, 1100, 24, [1])      # two kv heads of 64: the same bytes as interleaved 128-byte rows, 256 workgroups
+        run(128, 14, 2, 64, 4096, 6, [1])
+        run(256, 7, 1, 128, 1100, 12, [1])
