@@ -180,7 +180,8 @@ def _attention_block(x, wqkv, bqkv, wo, num_slots, num_kv, d):
     return torch.cat(outs, -1) @ wo.t()
 
 
-@pytest.mark.parametrize("H,Hkv,D,tp", [(14, 2, 64, 1), (14, 2, 64, 2), (28, 4, 128, 4), (28, 4, 128, 8), (8, 2, 64, 4),
+@pytest.mark.parametrize("H,Hkv,D,tp", [(14, 2, 64, 1), (14, 2, 64, 2), (14, 2, 64, 4), (14, 2, 64, 8),
+                                         (28, 4, 128, 2), (28, 4, 128, 4), (28, 4, 128, 8), (8, 2, 64, 4),
                                          (16, 8, 128, 8)])
 def test_head_layout_sum_over_ranks_equals_unsharded(H, Hkv, D, tp):
     """KV-head replication and zero-padded query slots (more ranks than KV heads, K shards of o_proj kept at
@@ -220,7 +221,8 @@ def test_head_layout_sum_over_ranks_equals_unsharded(H, Hkv, D, tp):
     assert torch.allclose(total, want, rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("inter,tp", [(4864, 2), (18944, 8), (18944, 4), (768, 4), (640, 3)])
+@pytest.mark.parametrize("inter,tp", [(4864, 2), (4864, 4), (4864, 8), (18944, 8), (18944, 4), (18944, 2),
+                                      (768, 4), (640, 3)])
 def test_mlp_uneven_shards_sum_over_ranks_equals_unsharded(inter, tp):
     """Intermediate columns are dealt in whole 128-column K-blocks; uneven shares are zero-padded (18944 = 148 blocks
     on 8 ranks -> 19,19,19,19,18,18,18,18)."""
