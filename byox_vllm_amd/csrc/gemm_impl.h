@@ -236,7 +236,9 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
       }
       if (stage && i % STAGE_EVERY == 0 && i / STAGE_EVERY < XV) {
         store_x_chunk(buf ^ 1, i / STAGE_EVERY);
+#ifndef NV_ABL_NOX
         load_x_chunk(kb_ahead, i / STAGE_EVERY);
+#endif
       }
     }
   };
@@ -430,7 +432,9 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
         u32x2 o;
         o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
         o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
+#ifndef NV_ABL_NOSTORE
         if (m < M && tile_live) *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+#endif
         float v[4] = {lo_f32<T>(o[0]), hi_f32<T>(o[0]), lo_f32<T>(o[1]), hi_f32<T>(o[1])};
         if (!tile_live) v[0] = v[1] = v[2] = v[3] = -INFINITY;
         float tm, ts;
@@ -483,6 +487,9 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
           u32x2 o;
           o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
           o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
+#ifdef NV_ABL_NOSTORE
+          if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)   // keeps the arithmetic alive, practically never stores
+#endif
           *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
         }
       }
