@@ -217,12 +217,12 @@ def test_engine_preemption_matches_oracle(golden, eager):
         assert agree >= 0.8 * sum(len(x) for x in want)
 
 
-@pytest.mark.parametrize("tp", [2, 4])
+@pytest.mark.parametrize("tp", [2, 4, 8])
 @pytest.mark.parametrize("collectives", ["gloo", "xgmi-eager", "xgmi-graph"])
 def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypatch):
     """The whole tensor-parallel runtime on one GPU: worker spawn, shared-memory control messages, sharded weights
     (tp=2: the reference's split; tp=4 on 4/2 heads: KV-head replication, a zero-padded query slot per rank, two
-    ranks with an all-zero MLP shard), all-reduce and logits gather.  The ranks share the device, so the process
+    ranks with an all-zero MLP shard; tp=8: ranks that hold no real query head at all), all-reduce and logits gather.  The ranks share the device, so the process
     group is gloo (NV_DIST_BACKEND; RCCL needs one GPU per rank).  `gloo`: the all-reduces take a host hop and the
     steps run eagerly.  `xgmi-*`: the all-reduces run through nv_allreduce_add_rmsnorm / nv_allreduce on buffers the
     ranks map into each other by hipIpc handles, eagerly and inside every rank's captured decode graph (the path a
@@ -250,6 +250,43 @@ def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypa
         agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
         assert agree >= 0.8 * sum(len(x) for x in want)
     assert all(len(x) == 8 for x in got)
+
+
+@pytest.mark.parametrize("tp", [4, 8])
+def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
+    """The layer geometry of the metric configuration (Qwen2-0.5B: 14 query / 2 KV heads of 64, hidden 896,
+    intermediate 4864 = 38 K-blocks, int4 weights, two layers, a small vocabulary) sharded over 4 and 8 ranks that share
+    the GPU: more ranks than KV heads (each KV head on tp/2 ranks with 4+3 / 2+2+2+1 query heads, zero-padded slots),
+    o_proj K shards padded to 128, MLP K-blocks dealt 10,10,9,9 / 5,5,5,5,5,5,4,4.  Greedy tokens against the CPU oracle
+    on the fake-quantised weights: what bench.py --gpus 4 / 8 runs by default, checked for its arithmetic."""
+    from types import SimpleNamespace
+
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
+    get_rope.cache_clear()
+    cfg = SimpleNamespace(vocab_size=1024, hidden_size=896, intermediate_size=4864, num_hidden_layers=2,
+                          num_attention_heads=14, num_key_value_heads=2, head_dim=64, max_position_embeddings=128,
+                          rms_norm_eps=1e-6, hidden_act="silu", attention_bias=True, rope_theta=1000000.0,
+                          rope_scaling=None, tie_word_embeddings=True, dtype=torch.bfloat16)
+    weights = OM.random_weights(cfg, seed=3)
+    rng = np.random.RandomState(17)
+    prompts = [rng.randint(0, 1024, size=n).tolist() for n in (9, 30, 17)]
+    want, margin = _oracle_generate(cfg, OM.fake_quantize(weights, 4), prompts, max_tokens=6, num_blocks=16)
+    llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=BS,
+              num_kvcache_blocks=16, enforce_eager=True, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
+              tensor_parallel_size=tp)
+    try:
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), use_tqdm=False)
+    finally:
+        llm._exit()
+    got = [o["token_ids"] for o in outs]
+    assert all(len(x) == 6 for x in got)
+    if margin > LOGIT_TOL:
+        assert got == want
+    else:
+        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
+        assert agree >= 0.8 * sum(len(x) for x in want)
 
 
 def test_graph_replay_equals_eager(golden):
