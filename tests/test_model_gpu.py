@@ -289,6 +289,40 @@ def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
         assert agree >= 0.8 * sum(len(x) for x in want)
 
 
+def test_engine_tensor_parallel_qwen2_7b_geometry_on_8_ranks(monkeypatch):
+    """BASELINE configuration 5's shards at their own shapes: one Qwen2-7B layer (28 query / 4 KV heads of 128, hidden
+    3584, intermediate 18944 = 148 K-blocks dealt 19,19,19,19,18,18,18,18, int4) over 8 ranks sharing the GPU, a small
+    vocabulary.  Greedy tokens against the CPU oracle on the fake-quantised weights."""
+    from types import SimpleNamespace
+
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
+    get_rope.cache_clear()
+    cfg = SimpleNamespace(vocab_size=1024, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1,
+                          num_attention_heads=28, num_key_value_heads=4, head_dim=128, max_position_embeddings=128,
+                          rms_norm_eps=1e-6, hidden_act="silu", attention_bias=True, rope_theta=1000000.0,
+                          rope_scaling=None, tie_word_embeddings=False, dtype=torch.bfloat16)
+    weights = OM.random_weights(cfg, seed=5)
+    rng = np.random.RandomState(23)
+    prompts = [rng.randint(0, 1024, size=n).tolist() for n in (11, 25)]
+    want, margin = _oracle_generate(cfg, OM.fake_quantize(weights, 4), prompts, max_tokens=4, num_blocks=16)
+    llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=BS,
+              num_kvcache_blocks=16, enforce_eager=True, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
+              tensor_parallel_size=8)
+    try:
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True), use_tqdm=False)
+    finally:
+        llm._exit()
+    got = [o["token_ids"] for o in outs]
+    assert all(len(x) == 4 for x in got)
+    if margin > LOGIT_TOL:
+        assert got == want
+    else:
+        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
+        assert agree >= 0.8 * sum(len(x) for x in want)
+
+
 def test_graph_replay_equals_eager(golden):
     """A captured decode step (padded batch, staged inputs) returns the same logits as the eager step."""
     _, _, weights = _golden_weights(golden, "qwen2")
