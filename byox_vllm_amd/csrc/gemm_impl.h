@@ -342,6 +342,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
   // group 1 hands its half to group 0; in the second the direction is reversed, so each group ends up owning the
   // finished sums of one half of the tiles and both run the epilogue (the RoPE epilogue needs whole rows in one
   // place: there group 0 takes both halves).  a + b == b + a bit for bit, so the owner does not change the result.
+#ifndef NV_ABL_NOJOIN   // measurement aid: without the join each k-step group stores its own partial sums (wrong results)
   {
     f32x4* red = reinterpret_cast<f32x4*>(lds_raw);   // [RED_REGS][256 threads of the column group]
     const int t4 = wid * 64 + lane;
@@ -366,6 +367,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
       __syncthreads();
     }
   }
+#endif
   if (EPI == 3 && kg == 1) return;
   // tile idx = j * TM + i is finished by group 0 if it travelled in the first pass, else by group 1
   auto owns = [&](int idx) { return EPI == 3 || ((idx < RED_REGS) == (kg == 0)); };
