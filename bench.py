@@ -9,13 +9,20 @@ resident in HBM.  Rank 0 prints ONE JSON line; `value` is whole-job decode
 tokens/s, `roofline` prices the paged-attention kernel against HBM peak and
 `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
 
-For N > 1 launch under torch.distributed.run (one rank per GPU).  The default
-there is `--parallelism tp`: the reference's own split (column/row-sharded
-linears, RCCL all-reduce over xGMI captured inside the decode graph, logits
-gather), the SAME batch spread over N GPUs ("scaling": "strong").  After the
-timed tensor-parallel run the same job also times N independent replicas of the
-single-GPU step (no data-path collective) and reports that as the extra key
-`replicas_tok_s`; `--parallelism dp` makes the replicas the headline instead.
+For N > 1 the ranks run one per GPU under torch.distributed.run; started plainly
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) this script
+starts that launcher itself as a child process, before it touches a GPU, and
+passes the child's JSON line and exit code on (the reference spawns its own
+ranks too, nanovllm/engine/llm_engine.py:24-32).  The default there is
+`--parallelism tp`: the reference's own split (column/row-sharded linears,
+RCCL all-reduce over xGMI captured inside the decode graph, logits gather), the
+SAME batch spread over N GPUs ("scaling": "strong").  After the timed
+tensor-parallel run the same job also times the other all-reduce
+implementation (`--allreduce rccl` is the headline, the peer-memory all-reduce
+fused with add+RMSNorm is reported as `xgmi_allreduce_tok_s`, or the other way
+round) and N independent replicas of the single-GPU step (no data-path
+collective, `replicas_tok_s`); `--parallelism dp` makes the replicas the
+headline instead.
 """
 
 import argparse
@@ -149,40 +156,49 @@ def time_attention_kernel(runner, seqs, reps=10):
     return sorted(rounds)[len(rounds) // 2] * 1e-3 / launches, launches * 5
 
 
-def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0):
-    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample: the workload's own batch and
-    context, a few steps (a reduced batch would re-read the weights per 8 rows instead of per 128 and understate the
-    CPU); only the 7B geometry, whose setup alone takes minutes, is sampled at batch 8."""
+def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0, **geometry_overrides):
+    """The CPU oracle (a port of the reference's PyTorch path) on a bounded sample of the workload: its own batch and
+    context, a few decode steps.  Qwen2-0.5B runs whole.  Qwen2-7B would take minutes just to draw its weights, so a
+    TWO-layer model of the same geometry (full-size embedding and LM head) is timed and the step is extrapolated:
+    28 x (time of the layer stack / 2) + time of the LM head; every layer does the same work, and the sample says so."""
     from byox_vllm_amd.config import qwen2_config
     from oracle import model as OM
-    hf = qwen2_config(model_name, dtype=dtype)
-    sample_batch = batch if model_name != "qwen2-7b" else min(batch, 8)
+    full = qwen2_config(model_name, dtype=dtype, **geometry_overrides)      # overrides: tests shrink the vocabulary
+    sampled_layers = full.num_hidden_layers if model_name != "qwen2-7b" else 2
+    hf = qwen2_config(model_name, dtype=dtype, **dict(geometry_overrides, num_hidden_layers=sampled_layers))
     bs = 256
     t0 = time.perf_counter()
     weights = OM.random_weights(hf, seed=0)
     if quantization:
         weights = OM.fake_quantize(weights, 4 if quantization == "w4a16" else 8)
     blocks_per_seq = (context + 8) // bs + 1
-    om = OM.OracleQwen(hf, weights, bs, sample_batch * blocks_per_seq)
+    om = OM.OracleQwen(hf, weights, bs, batch * blocks_per_seq)
     for kv in om.kv:          # random history: one block drawn, the others copies (the timing does not see values)
         kv[:, :, :1].normal_()
         kv[:, :, 1:] = kv[:, :, :1]
-    tables = [list(range(i * blocks_per_seq, (i + 1) * blocks_per_seq)) for i in range(sample_batch)]
-    lens = [context] * sample_batch
-    ids = torch.randint(0, 10000, (sample_batch,))
+    tables = [list(range(i * blocks_per_seq, (i + 1) * blocks_per_seq)) for i in range(batch)]
+    lens = [context] * batch
+    ids = torch.randint(0, 10000, (batch,))
     setup = time.perf_counter() - t0
-    steps, spent = 0, 0.0
-    while steps < 1 or (spent < budget_s / 2 and steps < 4):
+    steps, t_layers, t_head = 0, 0.0, 0.0
+    while steps < 1 or (t_layers + t_head < budget_s / 2 and steps < 4):
         lens = [n + 1 for n in lens]
         ctx, pos = OM.decode_ctx(lens, tables, bs)
         t1 = time.perf_counter()
-        logits = om.compute_logits(om.forward(ids, pos, ctx), ctx)
+        hidden = om.forward(ids, pos, ctx)
+        t2 = time.perf_counter()
+        logits = om.compute_logits(hidden, ctx)
         ids = logits.float().argmax(-1)
-        spent += time.perf_counter() - t1
+        t_layers += t2 - t1
+        t_head += time.perf_counter() - t2
         steps += 1
-    return {"value": round(sample_batch * steps / spent, 2), "unit": "tokens/s", "cores": torch.get_num_threads(),
+    spent = t_layers * full.num_hidden_layers / sampled_layers + t_head
+    how = "whole model" if sampled_layers == full.num_hidden_layers else (
+        f"{sampled_layers} of {full.num_hidden_layers} decoder layers timed with the full embedding and LM head, layer "
+        f"time scaled by {full.num_hidden_layers}/{sampled_layers}")
+    return {"value": round(batch * steps / spent, 2), "unit": "tokens/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{steps} decode steps, batch {sample_batch} of {batch}, context {context}, same model/format, "
+            "sample": f"{steps} decode steps, batch {batch}, context {context}, same geometry/format, {how}; "
                       f"eager PyTorch CPU oracle (setup {setup:.0f}s not timed)"}
 
 
@@ -262,6 +278,21 @@ def run_generate_workload(args):
     print(json.dumps(line), flush=True)
 
 
+def self_launch(gpus: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` started plainly: run the N ranks under torch.distributed.run as a CHILD process (this
+    process has not touched a GPU and never will), pass the child's output through and return its exit code.  The
+    rendezvous port is one the kernel just handed out, so two jobs on one node do not meet."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,12 +303,15 @@ def main():
                     help="N > 1: tp (default) = one model sharded over the ranks; dp = one replica per rank")
     ap.add_argument("--no-replicas", action="store_true", help="tp: skip the extra replicas_tok_s leg")
     ap.add_argument("--allreduce", default="rccl", choices=["rccl", "xgmi"],
-                    help="tp: torch.distributed all-reduce (RCCL) or the library's all-reduce fused with add-RMSNorm")
+                    help="tp: which all-reduce the headline leg uses: torch.distributed (RCCL) or the library's own over "
+                         "peer-mapped memory, fused with add-RMSNorm; the other one is timed too and reported beside it")
+    ap.add_argument("--single-leg", action="store_true", help="tp: time only the --allreduce leg")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-7b", action="store_true", help="also time the CPU oracle for 7B (minutes of setup)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     if args.workload in GENERATE_WORKLOADS:
         args.steps, args.warmup = min(args.steps, 5), min(args.warmup, 1)
         torch.cuda.set_device(0)
@@ -288,7 +322,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # NV_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("NV_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -300,6 +334,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"      # where host-side control collectives keep their tensors
 
     from byox_vllm_amd.config import Config, qwen2_config
     from byox_vllm_amd.engine.model_runner import ModelRunner
@@ -317,22 +352,48 @@ def main():
     total_steps = args.warmup + args.steps + 2
     blocks_per_seq = (context + total_steps) // block_size + 1
 
-    def build(tp_size):
-        config = Config("synthetic", hf_config=hf, quantization=quantization, tensor_parallel_size=tp_size,
-                        kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
-                        max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
-                        max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
-                        enforce_eager=args.eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0,
-                        xgmi_allreduce=tp_size > 1 and args.allreduce == "xgmi")
+    def any_rank(flag: bool) -> bool:
+        """True on every rank if ``flag`` is set on any: the ranks decide TOGETHER whether a leg failed."""
+        if world == 1:
+            return flag
+        t = torch.tensor([1 if flag else 0], device=coll_dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item())
+
+    def construct(config, tp_size):
+        """ModelRunner(config) on every rank, or None on every rank (and the first error text) if any rank failed.
+        A constructor that raises has released what it had built (ModelRunner.__init__'s own exception path)."""
+        runner, error = None, None
         try:
-            r = ModelRunner(config, rank if tp_size > 1 else 0, None)
-        except Exception as e:   # a collective that cannot be captured on this stack must not cost the whole measurement
-            if tp_size == 1 or config.enforce_eager:
-                raise
-            print(f"[bench] rank {rank}: capturing the tensor-parallel decode graph failed ({e!r}); running the step "
-                  "eagerly (graph_captured: false)", file=sys.stderr, flush=True)
-            config.enforce_eager = True
-            r = ModelRunner(config, rank, None)
+            runner = ModelRunner(config, rank if tp_size > 1 else 0, None)
+        except Exception as e:
+            error = repr(e)
+        if any_rank(error is not None):
+            if runner is not None:
+                runner.exit()
+            return None, error or "another rank failed to build its runner"
+        return runner, None
+
+    def build(tp_size, allreduce="rccl"):
+        def config(eager):
+            return Config("synthetic", hf_config=hf, quantization=quantization, tensor_parallel_size=tp_size,
+                          kvcache_block_size=block_size, num_kvcache_blocks=batch * blocks_per_seq + 1,
+                          max_model_len=blocks_per_seq * block_size, max_num_seqs=batch,
+                          max_num_batched_tokens=max(8192, blocks_per_seq * block_size),
+                          enforce_eager=eager, graph_batch_sizes=[batch], seed=rank if tp_size == 1 else 0,
+                          xgmi_allreduce=tp_size > 1 and allreduce == "xgmi")
+        r, error = construct(config(args.eager), tp_size)
+        if r is None and tp_size > 1 and not args.eager:
+            # a collective that cannot be captured on this stack must not cost the whole measurement: every rank
+            # agreed that the capture failed (construct), every rank retries eagerly
+            print(f"[bench] rank {rank}: building the captured tensor-parallel step failed ({error}); running the "
+                  "step eagerly (graph_captured: false)", file=sys.stderr, flush=True)
+            from byox_vllm_amd.layers.rotary_embedding import get_rope
+            get_rope.cache_clear()
+            torch.cuda.empty_cache()
+            r, error = construct(config(True), tp_size)
+        if r is None:
+            raise RuntimeError(error)
         r.kv_cache.normal_()   # synthetic KV history: throughput does not depend on the values
         seqs_, next_block = make_sequences(batch, context, block_size)
         return r, seqs_, StepDriver(r, seqs_, next_block, tp_size)
@@ -352,32 +413,55 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         return dt
 
-    tp_error = None
-    try:
-        if tp > 1 and os.environ.get("NV_BENCH_FAIL_TP"):      # test hook: exercises the fallback below
-            raise RuntimeError("tensor-parallel leg failed on request (NV_BENCH_FAIL_TP)")
-        runner, seqs, driver = build(tp)
-        elapsed = timed(driver)
-    except Exception as e:
-        # A tensor-parallel step that fails on this stack (on every rank alike: a rank that fails alone leaves its
-        # peers inside a collective) must not cost the whole measurement: fall back to one replica per rank, say so.
-        if tp == 1:
-            raise
-        tp_error = repr(e)
-        print(f"[bench] rank {rank}: the tensor-parallel leg failed ({tp_error}); measuring {world} replicas instead",
-              file=sys.stderr, flush=True)
-        runner = driver = None
+    def leg(tp_size, allreduce="rccl"):
+        """Build + time one configuration; a failure is agreed on by all ranks -> (None, ..., error text)."""
+        runner = seqs = None
+        error = elapsed = None
+        try:
+            if tp_size > 1 and os.environ.get("NV_BENCH_FAIL_TP"):      # test hook: exercises the fallback below
+                raise RuntimeError("tensor-parallel leg failed on request (NV_BENCH_FAIL_TP)")
+            runner, seqs, driver = build(tp_size, allreduce)
+            elapsed = timed(driver)
+        except Exception as e:
+            error = repr(e)
+        if any_rank(error is not None):
+            if runner is not None:
+                try:
+                    runner.exit()
+                except Exception:
+                    pass
+            runner = None
+            torch.cuda.empty_cache()
+            from byox_vllm_amd.layers.rotary_embedding import get_rope
+            get_rope.cache_clear()
+            return None, None, None, error or "failed on another rank"
+        return runner, seqs, elapsed, None
+
+    def release(runner):
+        runner.exit()
         torch.cuda.empty_cache()
         from byox_vllm_amd.layers.rotary_embedding import get_rope
         get_rope.cache_clear()
+
+    tp_error = None
+    runner, seqs, elapsed, error = leg(tp, args.allreduce)
+    if runner is None:
+        # A tensor-parallel step that fails on this stack must not cost the whole measurement: fall back to one
+        # replica per rank, say so.
+        if tp == 1:
+            raise RuntimeError(error)
+        tp_error = error
+        print(f"[bench] rank {rank}: the tensor-parallel leg failed ({tp_error}); measuring {world} replicas instead",
+              file=sys.stderr, flush=True)
         tp = 1
-        runner, seqs, driver = build(1)
-        elapsed = timed(driver)
+        runner, seqs, elapsed, error = leg(1)
+        if runner is None:
+            raise RuntimeError(error)
 
     replicas = world // tp
     tokens = batch * args.steps * replicas
@@ -385,16 +469,9 @@ def main():
     kern_s, launches = time_attention_kernel(runner, seqs)
     kv_bytes = kv_bytes_per_launch(seqs, hf, tp)
     achieved = kv_bytes / kern_s / 1e9
-    # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950, + WRITE_SIZE) kept under
-    # profiles/: counters cannot be read from inside this process, so the measured traffic/algorithmic ratio
-    # of the same kernel and head geometry is applied to this run's byte count.
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_attn_decode_hbm_traffic.json")
-    if os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        for entry in [pmc] + pmc.get("others", []):
-            if entry["shape"]["D"] == hf.head_dim and entry["shape"]["Hkv"] == max(1, hf.num_key_value_heads // tp):
-                traffic = int(kv_bytes * entry["traffic_over_algorithmic"])
+    traffic, traffic_source = pmc_traffic(kv_bytes, hf.head_dim, max(1, hf.num_key_value_heads // tp))
+    graph_captured = not runner.enforce_eager
+    uses_comm = runner.comm is not None
 
     if rank == 0:
         line = {
@@ -407,41 +484,75 @@ def main():
             "dtype": dtype_name, "data": "synthetic (random weights, random KV history, random prompts)",
             "config": {"workload": args.workload, "geometry": model_name, "weight_format": quantization or dtype_name,
                        "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
-                       "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": not args.eager,
+                       "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": graph_captured,
                        "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "ranks": world,
+            # ranks that talk through RCCL: 0 when the job's process group is a rehearsal backend or there is one rank
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else 0,
             "backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
-            "graph_captured": not runner.enforce_eager,
-            "allreduce": (("nv_allreduce_add_rmsnorm (peer-mapped memory)" if runner.comm is not None else
+            "graph_captured": graph_captured,
+            "allreduce": (("nv_allreduce_add_rmsnorm (peer-mapped memory)" if uses_comm else
                            "torch.distributed all_reduce") if tp > 1 else None),
             "tp_error": tp_error,
             "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": bytes_step,
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ decode_combine_kernel)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": kv_bytes, "avg_launch_us": round(kern_s * 1e6, 2), "launches_timed": launches},
         }
-        if world == 1 and not args.no_cpu_baseline and (model_name != "qwen2-7b" or args.cpu_baseline_7b):
+        if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model_name, quantization, DTYPES[dtype_name], batch, context)
-    runner.exit()
+    release(runner)
+    del runner
+    if tp > 1 and not args.single_leg:
+        # the same tensor-parallel job with the other all-reduce, so that one lease of a multi-GPU node compares them
+        other = "xgmi" if args.allreduce == "rccl" else "rccl"
+        key = "xgmi_allreduce_tok_s" if other == "xgmi" else "rccl_allreduce_tok_s"
+        r2, _, e2, err2 = leg(tp, other)
+        if rank == 0:
+            line[key] = round(batch * args.steps / e2, 1) if r2 is not None else None
+            if r2 is not None:
+                line[key.replace("tok_s", "graph_captured")] = not r2.enforce_eager
+            else:
+                line[key.replace("tok_s", "error")] = err2
+        if r2 is not None:
+            release(r2)
+        del r2
     if tp > 1 and not args.no_replicas:
         # the same job as N independent replicas of the single-GPU step: what the hardware does with this workload
         # when no collective sits on the critical path (every rank takes part: the timing has barriers)
-        del runner, driver
-        torch.cuda.empty_cache()
-        from byox_vllm_amd.layers.rotary_embedding import get_rope
-        get_rope.cache_clear()
-        runner, seqs, driver = build(1)
-        rep_elapsed = timed(driver)
-        runner.exit()
+        r3, _, e3, err3 = leg(1)
         if rank == 0:
-            line["replicas_tok_s"] = round(batch * args.steps * world / rep_elapsed, 1)
+            line["replicas_tok_s"] = round(batch * args.steps * world / e3, 1) if r3 is not None else None
+        if r3 is not None:
+            release(r3)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kv_bytes, head_dim, num_kv_heads):
+    """HBM bytes per paged-attention launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE x 2 on
+    gfx950, + WRITE_SIZE): counters cannot be read from inside this process, so the measured traffic / algorithmic
+    ratio of the same kernel build and head geometry is applied to this run's byte count.  The file names the
+    kernel revision it was collected on; a library whose decode kernel has changed since gets no figure
+    -> (bytes or None, where the figure comes from)."""
+    from byox_vllm_amd._C import lib
+    tag = lib().nv_paged_attn_decode_kernel_tag().decode()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("attn_decode_hbm_traffic.json")),
+                       reverse=True):
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if pmc.get("kernel_tag") != tag:
+            continue
+        for entry in [pmc] + pmc.get("others", []):
+            if entry["shape"]["D"] == head_dim and entry["shape"]["Hkv"] == num_kv_heads:
+                return int(kv_bytes * entry["traffic_over_algorithmic"]), (
+                    f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE ratio {entry['traffic_over_algorithmic']} "
+                    f"of kernel revision {tag}, applied to this run's bytes")
+    return None, f"no PMC collection under profiles/ for kernel revision {tag} at D={head_dim}, Hkv={num_kv_heads}"
 
 
 if __name__ == "__main__":

@@ -62,6 +62,8 @@ class Config:
     graph_head: bool = True         # single rank: LM head + sampler inside the decode graph (False: forward only)
     graph_batch_sizes: Any = None   # optional list: capture decode graphs only for these padded batch sizes
     state_dict: Any = None   # optional in-memory checkpoint keyed by the packed parameter names
+    tp_port: int = 0         # rendezvous port of this engine's tensor-parallel ranks (0: LLMEngine picks a free one)
+    shm_name: str = ""       # name of this engine's control-message shared memory ("": LLMEngine derives a unique one)
 
     def __post_init__(self):
         assert self.kvcache_block_size % 16 == 0 and self.kvcache_block_size > 0

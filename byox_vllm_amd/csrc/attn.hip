@@ -989,6 +989,11 @@ static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
   return groups > 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
+// Revision of paged_decode_kernel's memory access pattern.  Bumped with every change that can alter the bytes a launch
+// moves; counter collections name the revision they were taken on, so a stale one is recognised.
+#define NV_PAGED_DECODE_KERNEL_TAG "decode-r02"
+extern "C" const char* nv_paged_attn_decode_kernel_tag(void) { return NV_PAGED_DECODE_KERNEL_TAG; }
+
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
   if (B <= 0 || Hkv <= 0) return 1;
   const int64_t groups = (int64_t)B * Hkv;

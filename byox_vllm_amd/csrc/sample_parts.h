@@ -11,7 +11,7 @@
 #include "common.h"
 
 #define SAMPLE_PART_COLS 64
-#define NV_SAMPLE_MAX_VOCAB (64 * 8192)   /* the draw keeps a row's part maxima and masses in 64 KB of LDS */
+#define NV_SAMPLE_MAX_VOCAB (64 * 8128)   /* the draw keeps a row's part maxima and masses (8 bytes per 64-column part) in dynamic LDS next to 512 bytes reserved for its static variables: 64 KB in all */
 #define SAMPLE_LOG2E 1.4426950408889634f
 
 struct SampleParts {     // [rows][P] each, P = ceil(V / 64)

@@ -31,6 +31,16 @@ class LLMEngine:
         names = {f.name for f in fields(Config)}
         config = Config(model, **{k: v for k, v in kwargs.items() if k in names})
         self.ps, self.events = [], []
+        if config.tensor_parallel_size > 1:
+            # this engine's own rendezvous port and control-channel name: a second engine on the node (replicas beside
+            # a tensor-parallel job, two tests) must not meet this one's ranks
+            import socket
+            if not config.tp_port:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    config.tp_port = sk.getsockname()[1]
+            if not config.shm_name:
+                config.shm_name = f"byox_vllm_amd_{os.getpid()}_{config.tp_port}"
         ctx = mp.get_context("spawn")
         for i in range(1, config.tensor_parallel_size):
             event = ctx.Event()

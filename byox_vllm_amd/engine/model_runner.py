@@ -25,7 +25,8 @@ from byox_vllm_amd.utils.context import get_context, reset_context, set_context
 from byox_vllm_amd.utils.loader import init_random_weights, load_model
 from byox_vllm_amd.utils.logging import logger
 
-SHM_NAME = "byox_vllm_amd"
+SHM_NAME = "byox_vllm_amd"      # defaults of a job that did not choose its own (Config.shm_name / Config.tp_port)
+TP_PORT = 2333
 SHM_BYTES = 1 << 22
 MAX_GRAPH_BS = 512
 
@@ -59,12 +60,17 @@ class ModelRunner:
         self.single_rank_rccl = self.world_size == 1 and os.environ.get("NV_TP_SINGLE_RANK_RCCL", "0") == "1"
         self._own_pg = False
         if self.single_rank_rccl and not dist.is_initialized():
-            dist.init_process_group("nccl", "tcp://127.0.0.1:2334", world_size=1, rank=0)
+            dist.init_process_group("nccl", f"tcp://127.0.0.1:{(getattr(config, 'tp_port', 0) or TP_PORT) + 1}",
+                                    world_size=1, rank=0)
             self._own_pg = True
         if self.world_size > 1 and not dist.is_initialized():
             # NV_DIST_BACKEND=gloo: rehearsal of the tensor-parallel runtime with the ranks sharing GPUs (RCCL wants one
             # device per rank); gloo collectives cannot be captured, so that mode runs eagerly
-            dist.init_process_group(os.environ.get("NV_DIST_BACKEND", "nccl"), "tcp://127.0.0.1:2333",
+            # the engine that spawned the ranks chose a free port and a shared-memory name of its own
+            # (LLMEngine.__init__), so several engines can live on one node; the reference's fixed
+            # tcp://localhost:2333 and "nanovllm" (model_runner.py:27,42) admit one
+            dist.init_process_group(os.environ.get("NV_DIST_BACKEND", "nccl"),
+                                    f"tcp://127.0.0.1:{getattr(config, 'tp_port', 0) or TP_PORT}",
                                     world_size=self.world_size, rank=rank)
             self._own_pg = True
         from byox_vllm_amd.layers.linear import set_comm, set_tp
@@ -94,6 +100,9 @@ class ModelRunner:
             self._allocate_kv_cache()
             if not self.enforce_eager:
                 self._capture_graphs()
+        except BaseException:
+            self._release_after_failed_init()
+            raise
         finally:
             # Back to the caller's default.  Where that is the CPU the device context is REMOVED rather than set to
             # "cpu" (the reference sets "cpu", model_runner.py:47): an installed context routes every later torch call
@@ -103,13 +112,39 @@ class ModelRunner:
             torch.set_default_dtype(default_dtype)
 
         if self.world_size > 1 and event is not None:
+            shm_name = getattr(config, "shm_name", "") or SHM_NAME
             if rank == 0:
-                self.shm = SharedMemory(name=SHM_NAME, create=True, size=SHM_BYTES)
+                self.shm = SharedMemory(name=shm_name, create=True, size=SHM_BYTES)
                 dist.barrier()
             else:
                 dist.barrier()
-                self.shm = SharedMemory(name=SHM_NAME)
+                self.shm = SharedMemory(name=shm_name)
                 self._loop()
+
+    def _release_after_failed_init(self) -> None:
+        """A constructor that raised half-way (an uncapturable collective, out of memory) gives back what it had
+        taken - decode graphs, KV cache, model, the peer-memory buffer and its mappings, its own process group - so
+        that the caller can build another runner in this process (bench.py retries eagerly, then falls back to
+        replicas).  No collective is issued here: the peers may be anywhere."""
+        from byox_vllm_amd.layers.linear import set_comm
+        self.graphs, self.graph_pool, self.graph_vars = {}, None, None
+        self.kv_cache = None
+        for module in (self.model.modules() if getattr(self, "model", None) is not None else ()):
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = module.v_cache = torch.tensor([])
+        self.model = None
+        set_comm(None)
+        if self.comm is not None:
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.comm.close()
+            self.comm = None
+        if self._own_pg and dist.is_initialized():
+            dist.destroy_process_group()
+            self._own_pg = False
+        torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ weights
     def _load_weights(self):
@@ -304,7 +339,18 @@ class ModelRunner:
         if self.rank == 0:
             token_ids = self.sampler(logits, dev(step["temperatures"])).tolist()
         reset_context()
+        self._check_comm()
         return token_ids
+
+    def _check_comm(self) -> None:
+        """Once per step, after the step's own synchronisation: a bounded wait of the peer-memory all-reduce that ran
+        out (a peer lost or late by seconds) leaves an error word in this rank's buffer and the kernels carry on with
+        whatever the staging buffers held.  Such a step must fail, not return tokens."""
+        if self.comm is not None:
+            code = self.comm.error()
+            if code:
+                raise RuntimeError(f"rank {self.rank}: the peer-memory all-reduce timed out waiting for a peer "
+                                   f"(nv_comm_error = {code}: phase {code - 1}); this step's hidden states are invalid")
 
     # ------------------------------------------------------------------ host -> device metadata
     def _to_device(self, t: torch.Tensor, device=None) -> torch.Tensor:

@@ -47,6 +47,13 @@ class PendingReduce:
         self.value = value
 
 
+def _require_device_weight(w, what: str) -> None:
+    """A LinearWeight built from host tensors would hand the kernel a host pointer (a GPU memory fault, not an error
+    code): refuse it here."""
+    if not w.data.is_cuda or (w.scales is not None and not w.scales.is_cuda):
+        raise RuntimeError(f"{what}: the weight's data/scales are on {w.data.device}; they must be device memory")
+
+
 def rms_norm(x, weight, eps, out=None):
     require_gpu(x, "rms_norm")
     hidden = x.size(-1)
@@ -115,6 +122,7 @@ def gemm_rope_kv_store(x, w, bias, positions, cos_sin, num_heads, num_kv_heads, 
     """qkv projection + bias + [head norms] + RoPE + KV-cache store in one launch -> qkv [T, (H+2Hkv)*D]
     (q and k rotated, v as projected).  ``w``: LinearWeight of the packed q|k|v rows."""
     require_gpu(x, "gemm_rope_kv_store")
+    _require_device_weight(w, "gemm_rope_kv_store")
     T, K = x.shape
     N = (num_heads + 2 * num_kv_heads) * head_dim
     assert K == w.in_features and N == w.out_features and x.stride(1) == 1 and x.dtype == w.dtype
@@ -233,6 +241,7 @@ def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=Fa
     silu_mul: ``w`` holds gate/up rows interleaved (LinearWeight.interleave_gate_up); returns silu(gate)*up [M, N/2].
     partial_out: return the split-K slabs as a Partials for a fused consumer instead of reducing them here."""
     require_gpu(x, "gemm")
+    _require_device_weight(w, "gemm")
     M, K = x.shape
     assert K == w.in_features and x.stride(1) == 1 and x.dtype == w.dtype
     N = w.out_features
@@ -291,6 +300,7 @@ def lm_head_sample(x, w, temperatures, seed=0, out=None, seed_offset=None, logit
     the sampler its statistics, so the logits are not read again; the tokens are those of ``sample(gemm(x, w), ...)``
     bit for bit, which is also what runs where the GEMM planner would split K (small vocabularies)."""
     require_gpu(x, "lm_head_sample")
+    _require_device_weight(w, "lm_head_sample")
     M, K = x.shape
     V = w.out_features
     assert K == w.in_features and x.stride(1) == 1 and x.dtype == w.dtype and w.scales is None

@@ -50,7 +50,9 @@ class ParallelLMHead(VocabParallelEmbedding):
         if self.weight is None:          # untied head whose row-major copy was released below
             return cached[1]
         w = self.weight.data
-        key = (w.data_ptr(), VocabParallelEmbedding.loads)
+        # rebuilt after every load through a weight_loader or init_random_weights (``loads``) and after an in-place
+        # write to the parameter itself (``_version``); writes through ``weight.data`` bypass both by design of torch
+        key = (w.data_ptr(), VocabParallelEmbedding.loads, self.weight._version)
         if cached is None or cached[0] != key:
             n, k = w.shape
             packed = LinearWeight.dense_tiled(w) if (n % 16 == 0 and k % 128 == 0) else LinearWeight.dense(w)

@@ -207,9 +207,11 @@ class LinearBase(nn.Module):
         with zeros get the zero weight and the scale a zero group quantises to."""
         q = getattr(self, "_quantized", None)
         if q is None:
-            shape = self.weight.shape
-            q = self._quantized = (torch.zeros(shape, dtype=torch.int8, device=values.device),
-                                   torch.zeros(shape, dtype=scales.dtype, device=values.device), quantization)
+            # staged where the dense parameter lives (the model's device): the kernel-side weight built from these
+            # in _pack must be device memory, whatever device the checkpoint reader handed the tensors on
+            shape, device = self.weight.shape, self.weight.device
+            q = self._quantized = (torch.zeros(shape, dtype=torch.int8, device=device),
+                                   torch.zeros(shape, dtype=scales.dtype, device=device), quantization)
         self.weight_loader(q[0], values, *shard_id)
         self.weight_loader(q[1], scales.repeat_interleave(128, dim=1), *shard_id)
 
@@ -229,7 +231,8 @@ class LinearBase(nn.Module):
         low = torch.where(g == 0, torch.full_like(g, float("inf")), g).amin(-1)
         mixed = (top != low) & (top != 0)
         scales = top.to(per_elem.dtype)
-        scales[top == 0] = torch.tensor(1e-8, dtype=torch.float32).to(per_elem.dtype)   # an all-zero group's scale
+        # an all-zero group's scale: what quantising a zero group gives (clamp_min(1e-8) rounded to the model dtype)
+        scales[top == 0] = torch.tensor(1e-8, dtype=torch.float32, device=per_elem.device).to(per_elem.dtype)
         if mixed.any():
             qmax = 7 if quantization == "w4a16" else 127
             w = (values.float().view(n, k // 128, 128) * g)[mixed].to(per_elem.dtype).float()   # the dense weight's value

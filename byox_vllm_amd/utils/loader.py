@@ -99,6 +99,9 @@ def init_random_weights(model: nn.Module, seed: int = 0) -> None:
         # per-shard draw keyed by name keeps memory bounded for 7B-class models
         g.manual_seed(seed * 1000003 + (hash_name(name) % 1000003))
         param.data.copy_(torch.randn(param.shape, generator=g, device=dev, dtype=torch.float32) * 0.02)
+    # the vocabulary matrices were rewritten without their weight_loader: layouts derived from them are stale
+    from byox_vllm_amd.layers.embed_head import VocabParallelEmbedding
+    VocabParallelEmbedding.loads += 1
 
 
 def hash_name(name: str) -> int:

@@ -106,6 +106,10 @@ int nv_kv_store(const void* key, int64_t key_row_stride, const void* value, int6
  * nv_paged_attn_decode_workspace_bytes(B, H, D, num_splits) bytes. */
 size_t nv_paged_attn_decode_workspace_bytes(int B, int H, int D, int num_splits);
 int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context);
+/* Revision name of the decode kernel's memory access pattern (no counterpart in the reference: flash-attn is a
+ * binary there).  Hardware-counter collections record it so that a measurement taken on another revision of the
+ * kernel is not applied to this one. */
+const char* nv_paged_attn_decode_kernel_tag(void);
 int nv_paged_attn_decode(const void* q, int64_t q_row_stride, const void* k_cache, const void* v_cache,
                          const int32_t* block_tables, int bt_stride, const int32_t* context_lens,
                          void* out, int64_t out_row_stride, void* workspace, size_t workspace_bytes,

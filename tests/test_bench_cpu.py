@@ -16,7 +16,14 @@ def test_cpu_baseline_runs_the_workloads_own_batch():
     r = bench.cpu_baseline("qwen2-0.5b", "w4a16", torch.bfloat16, batch=4, context=64, budget_s=2.0)
     assert r["kind"] == "port" and r["unit"] == "tokens/s" and r["value"] > 0
     assert r["cores"] == torch.get_num_threads()
-    assert "batch 4 of 4" in r["sample"] and "context 64" in r["sample"]
+    assert "batch 4," in r["sample"] and "context 64" in r["sample"] and "whole model" in r["sample"]
+
+
+def test_cpu_baseline_samples_layers_of_the_7b_geometry():
+    """Qwen2-7B: two decoder layers are timed and scaled to 28 (a small vocabulary keeps this test to seconds); the
+    sample text says so."""
+    r = bench.cpu_baseline("qwen2-7b", "w4a16", torch.bfloat16, batch=2, context=64, budget_s=1.0, vocab_size=512)
+    assert r["value"] > 0 and "2 of 28 decoder layers" in r["sample"] and "scaled by 28/2" in r["sample"]
 
 
 def test_default_workload_is_the_metric_configuration():

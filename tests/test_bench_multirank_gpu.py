@@ -1,5 +1,7 @@
-"""bench.py with two ranks on one GPU: the multi-rank launch path (torch.distributed.run, barrier, max over ranks,
-rank-0 JSON line) in both modes.  RCCL wants one device per rank, so the ranks talk over gloo (NV_BENCH_BACKEND)."""
+"""bench.py with two ranks on one GPU, started the way a user (or a driver that does not know about launchers) would:
+plain `python bench.py --gpus 2`.  The script starts torch.distributed.run itself as a child process; the ranks then
+go through barrier, max over ranks and the rank-0 JSON line in both parallel modes.  RCCL wants one device per rank,
+so the ranks talk over gloo (NV_BENCH_BACKEND) and the line has to say so."""
 
 import json
 import os
@@ -12,42 +14,54 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["dp", "default", "xgmi"])
-def test_bench_two_ranks(mode):
-    """`default` passes no --parallelism, as the round driver does: with more than one rank that is the tensor-parallel
-    split (one model over both ranks, all-reduce on the data path) plus the replicas leg."""
-    env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533" if mode == "dp" else "29534",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--workload", "qwen2-0.5b-fp16-b1-s128"] + (["--parallelism", "dp"] if mode == "dp" else []) + (
-               ["--allreduce", "xgmi"] if mode == "xgmi" else [])
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _bench(extra, env_extra=None, launcher=False):
+    env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:      # the round driver's form: an external launcher, one process per rank
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533"]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+            "--workload", "qwen2-0.5b-fp16-b1-s128"] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]          # exactly one line, from rank 0
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["dp", "default", "xgmi", "launcher"])
+def test_bench_two_ranks(mode):
+    """`default` passes no --parallelism, as the round driver does: with more than one rank that is the tensor-parallel
+    split (one model over both ranks, all-reduce on the data path), then the same job with the other all-reduce, then
+    the replicas leg.  `launcher`: the same under an external torch.distributed.run, the driver's documented form."""
+    extra = {"dp": ["--parallelism", "dp"], "default": [], "xgmi": ["--allreduce", "xgmi"], "launcher": ["--single-leg"]}[mode]
+    d = _bench(extra, launcher=mode == "launcher")
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 4 and d["value"] > 0
     assert d["scaling"] == ("weak" if mode == "dp" else "strong")
     assert d["config"]["parallelism"] == ("dp2" if mode == "dp" else "tp2")
-    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo"
-    assert d["graph_captured"] == (mode != "default")      # gloo collectives cannot be captured, the library's own can
+    # two ranks, none of them talking through RCCL: the label must not claim otherwise
+    assert d["rccl_ranks"] == 0 and d["backend"] == "gloo"
+    # gloo collectives cannot be captured, the library's own all-reduce can; the config block says what ran
+    captured = mode in ("dp", "xgmi")
+    assert d["graph_captured"] == captured and d["config"]["graph"] == captured
     assert ("replicas_tok_s" in d) == (mode != "dp") and d.get("replicas_tok_s", 1) > 0
+    if mode == "default":
+        assert d["allreduce"].startswith("torch.distributed")
+        assert d["xgmi_allreduce_tok_s"] > 0 and d["xgmi_allreduce_graph_captured"] is True
+    if mode == "xgmi":
+        assert d["allreduce"].startswith("nv_allreduce_add_rmsnorm")
+        assert d["rccl_allreduce_tok_s"] > 0 and d["rccl_allreduce_graph_captured"] is False
+    if mode == "launcher":
+        assert "xgmi_allreduce_tok_s" not in d
     assert "cpu_baseline" not in d                      # rank 0 times the CPU baseline at N = 1 only
+    assert d["roofline"]["traffic_source"]
 
 
 def test_bench_falls_back_to_replicas_when_the_tensor_parallel_leg_fails():
-    """A tensor-parallel step that raises on every rank must not cost the measurement: the line then reports one
-    replica per rank (weak scaling, dp2) and carries the error text."""
-    env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", NV_BENCH_FAIL_TP="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29535",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--workload", "qwen2-0.5b-fp16-b1-s128"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    """A tensor-parallel step that raises must not cost the measurement: the ranks agree on the failure, the line
+    reports one replica per rank (weak scaling, dp2) and carries the error text."""
+    d = _bench([], env_extra={"NV_BENCH_FAIL_TP": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert "NV_BENCH_FAIL_TP" in d["tp_error"] and "replicas_tok_s" not in d

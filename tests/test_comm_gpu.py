@@ -254,3 +254,23 @@ def test_processes_sharing_the_gpu_through_ipc_handles(tmp_path, world, rows):
             outs.append(p.communicate()[0])
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+
+
+def test_lost_peer_fails_the_step():
+    """A peer that never arrives: the bounded wait runs out (about two seconds), the kernel finishes, the error word is
+    set, and the runner's per-step check turns it into an exception instead of returning tokens computed from stale
+    staging buffers."""
+    from byox_vllm_amd.engine.model_runner import ModelRunner
+    comms = make_world(2, 16, 128)
+    x = torch.ones(4, 128, dtype=torch.bfloat16, device="cuda")
+    comms[0].all_reduce(x)                # rank 1 never calls
+    torch.cuda.synchronize()
+    assert comms[0].error() != 0
+    runner = ModelRunner.__new__(ModelRunner)
+    runner.comm, runner.rank = comms[0], 0
+    with pytest.raises(RuntimeError, match="timed out waiting for a peer"):
+        runner._check_comm()
+    runner.comm = None
+    runner._check_comm()                  # no communicator: nothing to check
+    for c in comms:
+        c.close()

@@ -182,8 +182,10 @@ def test_sampled_rows_match_the_oracle(full):
     truth = outs["truth"]
     hip_max, hip_rms = _errors(got[rows], truth)
     ref_max, ref_rms = _errors(outs["bf16"], truth)
+    direct_max, direct_rms = _errors(got[rows], outs["bf16"])
     print(f"{full.name}: logits vs fp64 truth: hip max {hip_max:.4f} rms {hip_rms:.5f} | bf16 oracle max {ref_max:.4f} "
-          f"rms {ref_rms:.5f} | logit std {truth.std().item():.3f}")
+          f"rms {ref_rms:.5f} | logit std {truth.std().item():.3f} max|logit| {truth.abs().max().item():.2f} || "
+          f"max|hip - bf16 oracle| {direct_max:.4f} rms {direct_rms:.5f}")
     assert hip_rms <= 1.5 * ref_rms and hip_max <= 1.5 * ref_max
     top2 = truth.topk(2, dim=-1).values
     for j in range(len(rows)):

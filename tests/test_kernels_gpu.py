@@ -583,6 +583,49 @@ def test_gemm_qwen2_7b_shapes(which, N, K, fmt, M):
             ulp_close(out, want_out, "bf16", ulps=1.0)
 
 
+# One rank's linears of Qwen2-7B sharded over 8 ranks (28/4 heads of 128: a KV head per rank pair, 4 query slots per
+# rank; 148 MLP K-blocks dealt 19/18, padded to 19), int4, at the 512 rows the 8-GPU configuration decodes with:
+# q|k|v (4 + 1 + 1) x 128 rows; o_proj K = 4 x 128; gate|up 2 x 19 x 128 rows with the SiLU epilogue; down_proj
+# K = 19 x 128; the vocabulary shard 152064 / 8.
+QWEN2_7B_TP8_SHARDS = [("qkv", 768, 3584, "w4a16"), ("o", 3584, 512, "w4a16"), ("gate_up", 4864, 3584, "w4a16"),
+                       ("down", 3584, 2432, "w4a16"), ("lm_head", 19008, 3584, "tiled")]
+
+
+@pytest.mark.parametrize("M", [128, 512])
+@pytest.mark.parametrize("which,N,K,fmt", QWEN2_7B_TP8_SHARDS)
+def test_gemm_qwen2_7b_tp8_shard_shapes(which, N, K, fmt, M):
+    """Every GEMM a rank of the 8-way tensor-parallel Qwen2-7B runs, with the planner's own tiles and split-K for the
+    shard shape, against the fp64 product of the dequantised weight rounded once; o/down also as slabs summed by the
+    following add-RMSNorm (what the captured step does before the all-reduce)."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    g = torch.Generator().manual_seed(N + M + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16)
+    if which == "gate_up":
+        w_ref = Q.dequantize_w4(*Q.quantize_w4(w))
+        want = L.silu_and_mul(_linear_fp64_rounded(x, w_ref)).float()
+        got = kernels.gemm(dev(x), LinearWeight.make(interleave_gate_up(dev(w)), fmt), silu_mul=True).float().cpu()
+        err = (got - want).abs()
+        unit = EPS["bf16"] * want.abs().clamp_min(1e-3) * 2
+        assert (err <= unit).float().mean().item() > 0.995 and (err <= 4 * unit).all()
+        return
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16) if which == "qkv" else None
+    lw, w_ref = _weights_for(fmt, w)
+    want = _linear_fp64_rounded(x, w_ref, bias)
+    got = kernels.gemm(dev(x), lw, None if bias is None else dev(bias))
+    ulp_close(got, want, "bf16", ulps=1.0)
+    if which in ("o", "down"):
+        res = torch.randn(M, N, generator=g).to(torch.bfloat16)
+        nw = (1 + 0.1 * torch.randn(N, generator=g)).to(torch.bfloat16)
+        parts = kernels.gemm(dev(x), lw, partial_out=True)
+        if isinstance(parts, kernels.Partials):
+            out, new_res = kernels.add_rms_norm(parts, dev(res), dev(nw), 1e-6)
+            want_out, want_res = L.add_rms_norm(got.cpu(), res, nw, 1e-6)
+            assert torch.equal(new_res.cpu(), want_res)
+            ulp_close(out, want_out, "bf16", ulps=1.0)
+
+
 @pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("M", [128, 512])
 @pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
@@ -771,8 +814,15 @@ def test_sampler_masked_logits_and_limits():
         assert toks[greedy].tolist() == lg.float().argmax(-1).cpu()[greedy].tolist()
         seen |= set(toks[~greedy].tolist())
     assert len(seen) >= 5
+    # the largest row the draw's LDS image admits (part statistics in dynamic LDS next to the kernel's statics), and
+    # one part more
+    vmax = 64 * 8128
+    big = torch.full((2, vmax), -4.0, dtype=torch.bfloat16)
+    big[0, vmax - 1], big[1, 77] = 3.0, 3.0
+    assert kernels.sample(dev(big), dev(torch.zeros(2))).tolist() == [vmax - 1, 77]
+    assert set(kernels.sample(dev(big), dev(torch.full((2,), 0.05)), seed=1).tolist()) == {vmax - 1, 77}
     with pytest.raises(RuntimeError, match="bad shape"):
-        kernels.sample(dev(torch.zeros(1, 64 * 8192 + 64, dtype=torch.bfloat16)), dev(torch.ones(1)))
+        kernels.sample(dev(torch.zeros(1, vmax + 1, dtype=torch.bfloat16)), dev(torch.ones(1)))
 
 
 @pytest.mark.parametrize("name", list(DT))

@@ -6,6 +6,7 @@ import torch
 
 from oracle import layers as L
 from oracle import model as OM
+from oracle_tokens import check_tokens_against_oracle
 
 pytestmark = pytest.mark.gpu
 BS = 16
@@ -87,14 +88,17 @@ def test_whole_model_vs_reference_goldens(golden, style, dname):
         ref = torch.from_numpy(g[key + "logits_" + name])
         e_hip, e_ref = (logits - truth).abs(), (ref - truth).abs()
         report.append((name, e_hip.max().item(), e_ref.max().item(), e_hip.pow(2).mean().sqrt().item(),
-                       e_ref.pow(2).mean().sqrt().item()))
+                       e_ref.pow(2).mean().sqrt().item(), (logits - ref).abs().max().item(), ref.abs().max().item()))
         assert e_hip.max().item() <= ERROR_RATIO * e_ref.max().item(), report[-1]
         assert e_hip.pow(2).mean().sqrt().item() <= ERROR_RATIO * e_ref.pow(2).mean().sqrt().item(), report[-1]
         assert (logits - ref).abs().max().item() < (LOGIT_TOL if dname == "bf16" else LOGIT_TOL / 8), name
         if name == "prefill":
             assert logits.argmax(-1).tolist() == ref.argmax(-1).tolist()
     for row in report:
-        print("%s %s %-15s max hip %.4f ref %.4f | rms hip %.5f ref %.5f" % ((style, dname) + row))
+        # the last two columns are the plain distance between the two 16-bit paths (HIP vs the reference's own logits)
+        # and the size of the logits it is measured on
+        print("%s %s %-15s vs fp64 truth: max hip %.4f ref %.4f | rms hip %.5f ref %.5f || max|hip - reference| %.4f "
+              "at max|logit| %.2f" % ((style, dname) + row))
     # the paged KV cache holds what the oracle's holds (v = the projection's output: one GEMM away from the
     # normalised embedding, so equal up to one rounding of the model dtype where the summation order matters)
     om = OM.OracleQwen(cfg, weights, BS, 12)
@@ -134,74 +138,49 @@ def test_quantised_model_vs_oracle(golden, quant, bits):
     runner.exit()
 
 
-def _oracle_generate(cfg, weights, prompts, max_tokens, num_blocks):
-    """Greedy generation with the CPU oracle under the product's own scheduler/block manager."""
-    from types import SimpleNamespace
-
-    from byox_vllm_amd.engine.scheduler import Scheduler
-    from byox_vllm_amd.engine.sequence import Sequence
-    from byox_vllm_amd.sampling_params import SamplingParams
-    om = OM.OracleQwen(cfg, weights, BS, num_blocks)
-    sched = Scheduler(SimpleNamespace(max_num_seqs=8, max_num_batched_tokens=256, eos=-1,
-                                      num_kvcache_blocks=num_blocks, kvcache_block_size=BS))
-    seqs = [Sequence(p, BS, SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True)) for p in prompts]
-    for s in seqs:
-        sched.add(s)
-    margins = []
-    while not sched.is_finished():
-        batch, is_prefill = sched.schedule()
-        if is_prefill:
-            ctx, pos = OM.prefill_ctx([len(s) for s in batch], [s.block_table for s in batch], BS,
-                                      cached=[s.num_cached_tokens for s in batch])
-            ids = torch.tensor([t for s in batch for t in s[s.num_cached_tokens:]])
-        else:
-            ctx, pos = OM.decode_ctx([len(s) for s in batch], [s.block_table for s in batch], BS)
-            ids = torch.tensor([s.last_token for s in batch])
-        logits = om.compute_logits(om.forward(ids, pos, ctx), ctx).float()
-        top2 = logits.topk(2, dim=-1).values
-        margins.extend((top2[:, 0] - top2[:, 1]).tolist())
-        sched.postprocess(batch, logits.argmax(-1).tolist())
-    return [s.completion_token_ids for s in seqs], min(margins)
+# (style, prompt seed, tokens per sequence, exact?)  The exact rows have no oracle top-2 gap below the tie tolerance
+# (seeds searched on the CPU), so the HIP engine's ids must be the oracle's greedy ids token for token.
+GREEDY_CASES = [("qwen2", 3, 12, False), ("qwen2", 147, 12, True), ("qwen3", 3, 12, False), ("qwen3", 377, 3, True)]
 
 
-@pytest.mark.parametrize("style", ["qwen2", "qwen3"])
+@pytest.mark.parametrize("style,seed,max_tokens,exact", GREEDY_CASES)
 @pytest.mark.parametrize("eager", [True, False])
-def test_engine_greedy_tokens_match_oracle(golden, eager, style):
-    """LLM.generate (scheduler + block manager + runner, hipGraph decode when eager=False) vs the oracle loop."""
+def test_engine_greedy_tokens_match_oracle(golden, eager, style, seed, max_tokens, exact):
+    """LLM.generate (scheduler + block manager + runner, hipGraph decode when eager=False): every emitted token id
+    against the teacher-forced oracle (tests/oracle_tokens.py)."""
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     get_rope.cache_clear()
     _, _, weights = _golden_weights(golden, style)
     cfg = OM.tiny_config(style, torch.bfloat16)
-    rng = np.random.RandomState(3)
+    rng = np.random.RandomState(seed)
     prompts = [rng.randint(0, 256, size=n).tolist() for n in (5, 19, 33, 16)]
-    want, margin = _oracle_generate(cfg, weights, prompts, max_tokens=12, num_blocks=16)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=16,
               enforce_eager=eager, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8)
-    outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True), use_tqdm=False)
+    try:
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True), use_tqdm=False)
+    finally:
+        llm._exit()
     got = [o["token_ids"] for o in outs]
-    llm._exit()
-    if margin > LOGIT_TOL:
-        assert got == want
-    else:  # a near-tie in the oracle's logits: ids are only defined up to that tie, compare the agreeing prefix
-        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
-        assert agree >= 0.8 * sum(len(x) for x in want)
-    assert all(len(x) == 12 for x in got)
+    assert all(len(x) == max_tokens for x in got)
+    check_tokens_against_oracle(cfg, weights, prompts, got, block_size=BS, num_blocks=16, expect_exact=exact,
+                                label=f"greedy {style} seed {seed} {'eager' if eager else 'graph'}")
 
 
+@pytest.mark.parametrize("seed,exact", [(17, False), (20, True)])
 @pytest.mark.parametrize("eager", [True, False])
-def test_engine_preemption_matches_oracle(golden, eager):
+def test_engine_preemption_matches_oracle(golden, eager, seed, exact):
     """Too few KV blocks for the batch: the scheduler preempts and later re-prefills sequences (with prefix-cache
-    hits on their own earlier blocks); tokens still equal the oracle loop driven by the same scheduler."""
+    hits on their own earlier blocks); every token still is the oracle's under the same scheduler (seed 20: a run
+    without near-ties, ids identical)."""
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     get_rope.cache_clear()
     _, _, weights = _golden_weights(golden, "qwen2")
     cfg = OM.tiny_config("qwen2", torch.bfloat16)
-    rng = np.random.RandomState(17)
+    rng = np.random.RandomState(seed)
     prompts = [rng.randint(0, 256, size=n).tolist() for n in (30, 28, 25)]
     blocks = 9          # 3 sequences x up to 5 blocks of 16 would need 15
-    want, margin = _oracle_generate(cfg, weights, prompts, max_tokens=40, num_blocks=blocks)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=blocks,
               enforce_eager=eager, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8)
     try:
@@ -210,11 +189,8 @@ def test_engine_preemption_matches_oracle(golden, eager):
         llm._exit()
     got = [o["token_ids"] for o in outs]
     assert all(len(x) == 40 for x in got)
-    if margin > LOGIT_TOL:
-        assert got == want
-    else:
-        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
-        assert agree >= 0.8 * sum(len(x) for x in want)
+    check_tokens_against_oracle(cfg, weights, prompts, got, block_size=BS, num_blocks=blocks, expect_exact=exact,
+                                label=f"preemption seed {seed} {'eager' if eager else 'graph'}")
 
 
 @pytest.mark.parametrize("tp", [2, 4, 8])
@@ -235,7 +211,6 @@ def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypa
     cfg = OM.tiny_config("qwen2", torch.bfloat16)
     rng = np.random.RandomState(11)
     prompts = [rng.randint(0, 256, size=n).tolist() for n in (7, 21, 16)]
-    want, margin = _oracle_generate(cfg, weights, prompts, max_tokens=8, num_blocks=16)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=16,
               enforce_eager=collectives != "xgmi-graph", max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
               tensor_parallel_size=tp, xgmi_allreduce=collectives != "gloo")
@@ -244,12 +219,10 @@ def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypa
     finally:
         llm._exit()
     got = [o["token_ids"] for o in outs]
-    if margin > LOGIT_TOL:
-        assert got == want
-    else:
-        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
-        assert agree >= 0.8 * sum(len(x) for x in want)
     assert all(len(x) == 8 for x in got)
+    # prompt seed 11: no oracle top-2 gap below 0.11, so the ids must be identical
+    check_tokens_against_oracle(cfg, weights, prompts, got, block_size=BS, num_blocks=16, expect_exact=True,
+                                label=f"tp{tp} {collectives}")
 
 
 @pytest.mark.parametrize("tp", [4, 8])
@@ -272,7 +245,6 @@ def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
     weights = OM.random_weights(cfg, seed=3)
     rng = np.random.RandomState(17)
     prompts = [rng.randint(0, 1024, size=n).tolist() for n in (9, 30, 17)]
-    want, margin = _oracle_generate(cfg, OM.fake_quantize(weights, 4), prompts, max_tokens=6, num_blocks=16)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=BS,
               num_kvcache_blocks=16, enforce_eager=True, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
               tensor_parallel_size=tp)
@@ -282,11 +254,9 @@ def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
         llm._exit()
     got = [o["token_ids"] for o in outs]
     assert all(len(x) == 6 for x in got)
-    if margin > LOGIT_TOL:
-        assert got == want
-    else:
-        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
-        assert agree >= 0.8 * sum(len(x) for x in want)
+    # prompt seed 17: smallest oracle top-2 gap 0.17, ids identical
+    check_tokens_against_oracle(cfg, OM.fake_quantize(weights, 4), prompts, got, block_size=BS, num_blocks=16,
+                                expect_exact=True, label=f"metric geometry tp{tp}")
 
 
 def test_engine_tensor_parallel_qwen2_7b_geometry_on_8_ranks(monkeypatch):
@@ -306,7 +276,6 @@ def test_engine_tensor_parallel_qwen2_7b_geometry_on_8_ranks(monkeypatch):
     weights = OM.random_weights(cfg, seed=5)
     rng = np.random.RandomState(23)
     prompts = [rng.randint(0, 1024, size=n).tolist() for n in (11, 25)]
-    want, margin = _oracle_generate(cfg, OM.fake_quantize(weights, 4), prompts, max_tokens=4, num_blocks=16)
     llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=BS,
               num_kvcache_blocks=16, enforce_eager=True, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8,
               tensor_parallel_size=8)
@@ -316,11 +285,79 @@ def test_engine_tensor_parallel_qwen2_7b_geometry_on_8_ranks(monkeypatch):
         llm._exit()
     got = [o["token_ids"] for o in outs]
     assert all(len(x) == 4 for x in got)
-    if margin > LOGIT_TOL:
-        assert got == want
-    else:
-        agree = sum(a == b for x, y in zip(got, want) for a, b in zip(x, y))
-        assert agree >= 0.8 * sum(len(x) for x in want)
+    # prompt seed 23: smallest oracle top-2 gap 0.125, ids identical
+    check_tokens_against_oracle(cfg, OM.fake_quantize(weights, 4), prompts, got, block_size=BS, num_blocks=16,
+                                expect_exact=True, label="qwen2-7b geometry tp8")
+
+
+def test_config5_qwen2_7b_tp8_batch512_captured_graph_with_fused_allreduce(monkeypatch):
+    """BASELINE configuration 5 at its own sizes on one GPU: Qwen2-7B layer geometry (two layers, int4), 8 ranks sharing
+    the device, **512 sequences** decoding through every rank's captured graph with the peer-memory all-reduce fused
+    with add+RMSNorm inside it (M = 512 GEMMs at the shard shapes, nv_allreduce_add_rmsnorm at 512 rows, the
+    512-sequence control message through shared memory, KV blocks of 256).  What one GPU cannot show is RCCL and the
+    xGMI links themselves.  Rows of a step are independent, so four of the 512 sequences are verified token by token
+    against the teacher-forced oracle run on those four alone."""
+    from types import SimpleNamespace
+
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
+    get_rope.cache_clear()
+    cfg = SimpleNamespace(vocab_size=1024, hidden_size=3584, intermediate_size=18944, num_hidden_layers=2,
+                          num_attention_heads=28, num_key_value_heads=4, head_dim=128, max_position_embeddings=512,
+                          rms_norm_eps=1e-6, hidden_act="silu", attention_bias=True, rope_theta=1000000.0,
+                          rope_scaling=None, tie_word_embeddings=False, dtype=torch.bfloat16)
+    weights = OM.random_weights(cfg, seed=5)
+    rng = np.random.RandomState(29)
+    batch, block, max_tokens = 512, 256, 3
+    prompts = [rng.randint(0, 1024, size=int(n)).tolist() for n in rng.randint(16, 33, size=batch)]
+    llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=block,
+              num_kvcache_blocks=batch + 8, enforce_eager=False, graph_batch_sizes=[batch], max_model_len=512,
+              max_num_batched_tokens=16384, max_num_seqs=batch, tensor_parallel_size=8, xgmi_allreduce=True)
+    try:
+        runner = llm.model_runner
+        assert runner.comm is not None and not runner.enforce_eager and list(runner.graphs) == [batch]
+        replays = []
+        real = runner._replay
+        runner._replay = lambda bs: (replays.append(bs), real(bs))[1]
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=max_tokens, ignore_eos=True), use_tqdm=False)
+    finally:
+        llm._exit()
+    got = [o["token_ids"] for o in outs]
+    assert all(len(x) == max_tokens for x in got)
+    assert replays == [batch] * (max_tokens - 1), "the decode steps must have replayed the 512-row graph"
+    rows = [0, 137, 300, batch - 1]
+    check_tokens_against_oracle(cfg, OM.fake_quantize(weights, 4), [prompts[i] for i in rows], [got[i] for i in rows],
+                                block_size=block, num_blocks=8, max_num_batched_tokens=16384,
+                                label="config 5 (7B int4 tp8 b512, graph + fused all-reduce), sampled rows")
+
+
+def test_kv_cache_sized_from_free_memory(golden):
+    """num_kvcache_blocks left unset: the runner sizes the cache from the device's memory after its warm-up prefill,
+    (total x gpu_memory_utilization - used - peak + current) // block_bytes as nanovllm/engine/model_runner.py:115-150
+    does, and decodes through it."""
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    budget = 1 << 30                                   # ask for what is in use now plus 1 GiB
+    runner = make_runner(cfg, weights, num_blocks=-1, gpu_memory_utilization=(total - free + budget) / total)
+    try:
+        block_bytes = 2 * cfg.num_hidden_layers * BS * cfg.num_key_value_heads * cfg.head_dim * 2
+        blocks = runner.config.num_kvcache_blocks
+        assert runner.kv_cache.shape == (2, cfg.num_hidden_layers, blocks, BS, cfg.num_key_value_heads, cfg.head_dim)
+        # the model's own weights and what the warm-up left allocated come out of the 1 GiB; most of it is cache
+        assert 0.5 * budget < blocks * block_bytes <= budget, (blocks, block_bytes)
+        rng = np.random.RandomState(2)
+        seq = Sequence(rng.randint(0, 256, size=21).tolist(), BS, SamplingParams(temperature=0.0, max_tokens=4))
+        seq.block_table = [blocks - 1, 0]              # the last block the sizing produced is usable
+        first = runner.run([seq], True)
+        seq.append_token(first[0])
+        assert len(runner.run([seq], False)) == 1
+    finally:
+        runner.exit()
 
 
 def test_graph_replay_equals_eager(golden):

@@ -37,10 +37,16 @@ def test_static_scratch_entry_point_matches_workspace_entry_point(D, H, Hkv):
         qd, kd, vd, cd, td = (t.cuda() for t in (q, kc, vc, ctx, tables))
         want_ws = kernels.paged_attn_decode(qd, kd, vd, cd, td, scale, num_splits=c["splits"])
         out = torch.full_like(qd, float("nan"))
+        torch.cuda.synchronize()
         before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        free_before, _ = torch.cuda.mem_get_info()             # hipMemGetInfo: the DEVICE's free memory
         kernels.paged_attn_decode_static(qd, kd, vd, cd, td, scale, out=out, num_splits=c["splits"])
         assert torch.cuda.memory_stats()["allocation.all.allocated"] == before      # torch's allocator was not asked
         torch.cuda.synchronize()
+        # and neither was the driver: a hipMalloc inside the library (of the 0.2-4.5 MB of partials these calls need,
+        # rounded up to the driver's 2 MiB granules) would show as less free device memory.  The very first call's
+        # hipGetSymbolAddress maps nothing: the array is part of the code object loaded with the library.
+        assert torch.cuda.mem_get_info()[0] >= free_before, "device memory was allocated during the call"
         assert torch.equal(out, want_ws), f"call {c} differs from the workspace entry point"
         want, want_abs = (OA.paged_attn_decode(q, kc, v, ctx, tables, scale) for v in (vc, vc.abs()))
         OA.check_close(out, want, want_abs, "static-scratch decode")
