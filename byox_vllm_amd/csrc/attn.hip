@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -61,6 +62,19 @@ struct ChunkRegs {
   uint32_t vv[8][AttnGeom<D>::NM / 2];       // token slot j: NM consecutive d values starting at NM*c
 };
 
+// A cached key/value row is read once per decode step by one wavefront, and a step's rows (every layer's cache) are
+// far more than the caches hold.  With 64-wide heads the loads of the decode walk carry the non-temporal hint, which
+// tells L2 and the Infinity Cache not to keep the lines: 128 sequences x 2 kv heads at context 1024 15.99 -> 14.36 us per
+// launch (8 wavefronts 15.45 -> 14.08), context 4000 5.3 -> 5.7 TB/s.  With 128-wide heads the hint lost 2 % (128 x 4
+// heads: 49.3 -> 50.3 us), so those keep the default policy.  NV_ATTN_NT=0 builds the default-policy form everywhere.
+#ifndef NV_ATTN_NT
+#define NV_ATTN_NT 1
+#endif
+template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 // Issue the loads of one chunk.  k_base/v_base point at element [row 0][this kv head][0], row_stride in
 // elements; rows[2] = first row of tile 0 / tile 1 (wave-uniform).  TAIL clamps rows to max_row (packed keys).
 template <typename T, int D, bool TAIL>
@@ -69,6 +83,7 @@ __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  constexpr bool NT = NV_ATTN_NT && D == 64;
   if constexpr (!TAIL) {
     // wave-uniform 64-bit row bases plus one 32-bit per-lane byte offset for K and one for V: the loads take the
     // scalar-base form and the addresses of a whole chunk cost two vector registers instead of two per load
@@ -78,16 +93,17 @@ __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k
     for (int tl = 0; tl < 2; ++tl) {
       const char* kb = reinterpret_cast<const char*>(k_base + rows[tl] * row_stride);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) r.kf[tl][ks] = *reinterpret_cast<const frag_t*>(kb + (koff + 64u * ks));
+      for (int ks = 0; ks < KS; ++ks)
+        r.kf[tl][ks] = __builtin_bit_cast(frag_t, stream_load<NT>(reinterpret_cast<const u32x4*>(kb + (koff + 64u * ks))));
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const char* vb = reinterpret_cast<const char*>(v_base + (rows[j >> 2] + (j & 3)) * row_stride);
       if constexpr (NM == 8) {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(vb + voff);
+        const u32x4 t = stream_load<NT>(reinterpret_cast<const u32x4*>(vb + voff));
         r.vv[j][0] = t[0]; r.vv[j][1] = t[1]; r.vv[j][2] = t[2]; r.vv[j][3] = t[3];
       } else {
-        const u32x2 t = *reinterpret_cast<const u32x2*>(vb + voff);
+        const u32x2 t = stream_load<NT>(reinterpret_cast<const u32x2*>(vb + voff));
         r.vv[j][0] = t[0]; r.vv[j][1] = t[1];
       }
     }
@@ -260,6 +276,25 @@ __device__ __forceinline__ int64_t paged_tile_row(const int32_t* bt_row, int tok
   return (int64_t)bt_row[blk] * block_size + off;
 }
 
+// Register sets a decode wavefront rotates through (chunks in flight behind the one being multiplied = sets - 1);
+// 1 = a single set ahead, handed over by copy.  A workgroup of up to 4 wavefronts leaves every wavefront a SIMD's
+// whole register file, so the depth is a question of memory-level parallelism only: NV_ATTN_DEPTH64 / NV_ATTN_DEPTH128
+// (build-time) set it for the measurements recorded with the kernel's launch heuristics.
+#ifndef NV_ATTN_DEPTH64
+#define NV_ATTN_DEPTH64 2
+#endif
+#ifndef NV_ATTN_DEPTH128
+#define NV_ATTN_DEPTH128 2
+#endif
+template <int D, int NW> constexpr int decode_depth() {
+  if (D == 64) return NW <= 4 ? NV_ATTN_DEPTH64 : 2;
+  return NW <= 4 ? NV_ATTN_DEPTH128 : 1;
+}
+template <typename F, int... Js>
+__device__ __forceinline__ bool ring_round(F& body, std::integer_sequence<int, Js...>) {
+  return (body(std::integral_constant<int, Js>{}) || ...);
+}
+
 // ------------------------------------------------------------------ decode
 // NW wavefronts per workgroup share one (sequence, kv head, split); wavefront w takes chunks
 // split*NW + w, + NW*splits, ...  Loads run one chunk ahead of the MFMAs and block-table lookups two ahead.
@@ -337,10 +372,11 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
   auto compute_full = [&](ChunkRegs<T, D>& r, int chunk) {
     chunk_compute<T, D, false, false>(st, r, qf, chunk << 5, n_keys, n_keys, scale2);
   };
-  if constexpr (D > 64) {
-    // 128-wide heads: with two alternating register sets the unrolled loop needs more than 256 registers (it spills
-    // and runs 13 % slower), so one set is loaded ahead and handed over by copy (the 16 KB chunks keep enough bytes
-    // in flight per wavefront regardless)
+  constexpr int DEPTH = decode_depth<D, NW>();
+  if constexpr (DEPTH == 1) {
+    // 128-wide heads in workgroups of 8+ wavefronts (two per SIMD, 256 registers each): two alternating register
+    // sets spill there (and run 13 % slower), so one set is loaded ahead and handed over by copy (the 16 KB chunks
+    // keep enough bytes in flight per wavefront regardless)
     int64_t rows_cur[2], rows_nxt[2] = {0, 0};
     lookup(ch, rows_cur);
     if (ch < n_chunks) {
@@ -363,31 +399,52 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
       }
     }
   } else {
-    int64_t rows_a[2], rows_b[2];
-    lookup(ch, rows_a);
-    if (ch < n_chunks) {
-      lookup(ch + step, rows_b);   // may describe a chunk that does not exist: then it is never used
-      ChunkRegs<T, D> ra, rb;
-      chunk_load<T, D, false>(ra, k_base, v_base, row_stride, rows_a, INT64_MAX);
-      while (true) {
-        if (ch + step >= n_chunks) {
-          compute(ra, ch);
-          break;
-        }
-        lookup(ch + 2 * step, rows_a);
-        chunk_load<T, D, false>(rb, k_base, v_base, row_stride, rows_b, INT64_MAX);
-        compute_full(ra, ch);
-        ch += step;
-        if (ch + step >= n_chunks) {
-          compute(rb, ch);
-          break;
-        }
-        lookup(ch + 2 * step, rows_b);
-        chunk_load<T, D, false>(ra, k_base, v_base, row_stride, rows_a, INT64_MAX);
-        compute_full(rb, ch);
-        ch += step;
-      }
+   int64_t rows0[2];
+   lookup(ch, rows0);   // issued before the context length has arrived: clamped index, used only if the chunk exists
+   if (ch < n_chunks) {
+    // DEPTH register sets in rotation: while set J is multiplied, the loads of the DEPTH - 1 following chunks are
+    // in flight in the other sets, and nothing is ever copied out of a set that is still being loaded (a copy would
+    // wait for its loads).  The steady-state body is straight-line code - its load is unconditional and the loop is
+    // left BEFORE a body whose load would not exist - so the compiler's s_waitcnt vmcnt counts are exact: an MFMA
+    // waits for the fragments of its own chunk only.  For the same reason the first DEPTH - 1 loads are issued
+    // unconditionally: a wavefront with fewer chunks than that reads its first chunk again (a cache hit).
+    ChunkRegs<T, D> rs[DEPTH];
+    int64_t rw[2];
+    chunk_load<T, D, false>(rs[0], k_base, v_base, row_stride, rows0, INT64_MAX);
+#pragma unroll
+    for (int j = 1; j < DEPTH - 1; ++j) {
+      int64_t rj[2];
+      lookup(ch + j * step, rj);
+      const bool exists = ch + j * step < n_chunks;
+      rj[0] = exists ? rj[0] : rows0[0];
+      rj[1] = exists ? rj[1] : rows0[1];
+      chunk_load<T, D, false>(rs[j], k_base, v_base, row_stride, rj, INT64_MAX);
     }
+    lookup(ch + (DEPTH - 1) * step, rw);   // rows of the next chunk to load (used only if that chunk exists)
+    // body J: multiply set J, refill the set that was multiplied last (J - 1) with the chunk DEPTH - 1 ahead; returns
+    // true once the remaining chunks (all loaded) have been multiplied
+    auto body = [&](auto jc) -> bool {
+      constexpr int J = decltype(jc)::value;
+      if (ch + (DEPTH - 1) * step >= n_chunks) {
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) {
+          if (ch < n_chunks) compute(rs[(J + d) % DEPTH], ch);
+          ch += step;
+        }
+        return true;
+      }
+      int64_t rn[2];
+      lookup(ch + DEPTH * step, rn);
+      chunk_load<T, D, false>(rs[(J + DEPTH - 1) % DEPTH], k_base, v_base, row_stride, rw, INT64_MAX);
+      compute_full(rs[J], ch);
+      ch += step;
+      rw[0] = rn[0];
+      rw[1] = rn[1];
+      return false;
+    };
+    while (!ring_round(body, std::make_integer_sequence<int, DEPTH>{})) {
+    }
+   }
   }
 
   // ---- merge the NW wavefronts of the workgroup.  The first NF = min(NW, 4) wavefronts finish the accumulator
@@ -986,12 +1043,13 @@ static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
     if (forced == 16) return D == 128 ? 8 : 16;
   }
   if (groups > 512 && max_tokens <= 512) return 1;
+  if (D == 64) return groups > 256 ? 2 : 8;       // with non-temporal loads 8 beat 4 at 256 groups (14.08 / 14.36 us)
   return groups > 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
 // Revision of paged_decode_kernel's memory access pattern.  Bumped with every change that can alter the bytes a launch
 // moves; counter collections name the revision they were taken on, so a stale one is recognised.
-#define NV_PAGED_DECODE_KERNEL_TAG "decode-r02"
+#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03a"
 extern "C" const char* nv_paged_attn_decode_kernel_tag(void) { return NV_PAGED_DECODE_KERNEL_TAG; }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {

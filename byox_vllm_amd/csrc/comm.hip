@@ -117,7 +117,9 @@ template <typename T>
 __device__ __forceinline__ u32x4 local_vec(const uint16_t* x, const float* part, int nparts, int64_t slab, int64_t elem) {
   if (part) {
     f32x4 acc[2];
-    slab_sum<2>(part + elem, slab, nparts, acc);
+    // batches of 4: with 8 slabs in flight per call site this kernel ran out of registers and took a stack frame,
+    // and a kernel that needs scratch memory is one more thing that can go wrong inside a captured graph
+    slab_sum<2, 4>(part + elem, slab, nparts, acc);
     return u32x4{pack2<T>(acc[0][0], acc[0][1]), pack2<T>(acc[0][2], acc[0][3]), pack2<T>(acc[1][0], acc[1][1]),
                  pack2<T>(acc[1][2], acc[1][3])};
   }

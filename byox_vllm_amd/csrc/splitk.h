@@ -36,13 +36,15 @@ __device__ __forceinline__ void slab_batch_n(const float* __restrict__ p, int64_
   }
 }
 
-// acc[i] = sum over z < nparts of the float4 at p + z * slab + 4 i   (nparts >= 1)
-template <int NV>
+// acc[i] = sum over z < nparts of the float4 at p + z * slab + 4 i   (nparts >= 1), loads issued in batches of up to
+// BATCH slabs (8, or 4 where the caller is short of registers); the order of the additions is the slab order either way
+template <int NV, int BATCH = 8>
 __device__ __forceinline__ void slab_sum(const float* __restrict__ p, int64_t slab, int nparts, f32x4 (&acc)[NV]) {
-  int n = nparts < 8 ? nparts : 8;
+  static_assert(BATCH == 4 || BATCH == 8, "batches of 4 or 8 slabs");
+  int n = nparts < BATCH ? nparts : BATCH;
   slab_batch_n<NV, true>(p, slab, n, acc);
-  for (int z = n; z < nparts; z += 8) {
-    n = nparts - z < 8 ? nparts - z : 8;
+  for (int z = n; z < nparts; z += BATCH) {
+    n = nparts - z < BATCH ? nparts - z : BATCH;
     slab_batch_n<NV, false>(p + z * slab, slab, n, acc);
   }
 }

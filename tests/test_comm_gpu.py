@@ -46,14 +46,71 @@ def rank_streams(world):
     return _STREAMS[:world]
 
 
+def wait_for_ranks(streams):
+    """Block until every in-process rank's stream has drained, and say so if the device-wide synchronize alone would
+    not have: each stream is queried first (a query submits whatever the runtime still holds back for that stream: a
+    rank whose launch is not submitted while the host blocks on its peer would leave that peer spinning), then
+    synchronised on its own."""
+    import time
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    pending = [not s.query() for s in streams]
+    for s in streams:
+        s.synchronize()
+    torch.cuda.synchronize()
+    if any(pending):
+        print(f"torch.cuda.synchronize() returned after {1e3 * (time.perf_counter() - t0):.2f} ms with work pending on the "
+              f"rank streams {pending}: waited for the streams one by one")
+
+
+_WORLDS = {}
+_REUSE_WORLDS = os.environ.get("NV_TEST_REUSE_WORLDS", "1") != "0"
+
+
 def make_world(world, max_rows, hidden):
+    """In-process ranks wired by pointer.  A world is built once per geometry and kept until the module's tests are
+    over, as an engine keeps its communicator for its lifetime: a rank's call counter carries on from test to test
+    (the protocol is indifferent to where it starts), and no buffer is freed while another test's may be mapped at
+    the same address."""
     from byox_vllm_amd.layers.comm import XgmiComm
+    key = (world, max_rows, hidden)
+    if _REUSE_WORLDS and key in _WORLDS:
+        return _WORLDS[key]
     comms = [XgmiComm(r, world, max_rows, hidden) for r in range(world)]
     for a in comms:
         for b in comms:
             if a is not b:
                 a.set_peer(b.rank, b)
+    if _REUSE_WORLDS:
+        _WORLDS[key] = comms
     return comms
+
+
+def release(comms):
+    if not _REUSE_WORLDS:
+        for c in comms:
+            c.close()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_worlds():
+    yield
+    torch.cuda.synchronize()
+    for comms in _WORLDS.values():
+        for c in comms:
+            c.close()
+    _WORLDS.clear()
+
+
+def _describe_difference(mine, theirs, want, comms, rows):
+    """Which rows differ between two ranks' outputs, who owns them, and which of the two matches the oracle."""
+    bad = (mine != theirs).any(dim=1).nonzero().flatten().tolist()
+    owners = {r: comms[r].owned_rows(rows) for r in range(len(comms))}
+    near = lambda t: [bool(ulp_ok(t[i], want[i], ulps=2.0)) for i in bad[:8]]  # noqa: E731
+    zero = lambda t: [bool((t[i] == 0).all().item()) for i in bad[:8]]  # noqa: E731
+    return (f"memory {comms[0].memory_kind}; {len(bad)} rows differ, first {bad[:8]}; owned rows {owners}; this rank "
+            f"matches the oracle there: {near(mine)}, rank 0 does: {near(theirs)}; all-zero rows here {zero(mine)}, "
+            f"on rank 0 {zero(theirs)}")
 
 
 def test_single_rank_equals_add_rmsnorm():
@@ -117,11 +174,12 @@ def test_ranks_on_streams_match_the_oracle(world, rows, hidden, captured):
                     graphs[r].replay()
         else:
             launch_all()
-        torch.cuda.synchronize()
+        wait_for_ranks(streams)
         assert all(c.error() == 0 for c in comms), "a rank waited for a peer in vain"
         want_out, want_res = oracle(xs, res, w, 1e-6)
         for r in range(world):
-            assert torch.equal(outs[r], outs[0]), f"rank {r} holds other bits than rank 0 (iteration {it})"
+            assert torch.equal(outs[r], outs[0]), (f"rank {r} holds other bits than rank 0 (iteration {it}): "
+                                                   + _describe_difference(outs[r], outs[0], want_out, comms, rows))
             lo, hi = comms[r].owned_rows(rows)
             assert torch.equal(res_dev[r][lo:hi].cpu(), want_res[lo:hi]), "owned residual rows: one add, one rounding"
             mask = torch.ones(rows, dtype=torch.bool)
@@ -130,8 +188,7 @@ def test_ranks_on_streams_match_the_oracle(world, rows, hidden, captured):
         # the residual rows above pin the reduction bit for bit; the normalised rows go through rsqrt and two
         # roundings, where the device's 1/sqrt and the oracle's rsqrt may differ in the last place
         assert ulp_ok(outs[0], want_out, ulps=2.0), (outs[0].float().cpu() - want_out.float()).abs().max()
-    for c in comms:
-        c.close()
+    release(comms)
 
 
 def test_plain_all_reduce_and_split_k_slabs_as_input():
@@ -147,7 +204,7 @@ def test_plain_all_reduce_and_split_k_slabs_as_input():
     for r in range(world):
         with torch.cuda.stream(streams[r]):
             outs[r] = comms[r].all_reduce(xs[r].cuda())
-    torch.cuda.synchronize()
+    wait_for_ranks(streams)
     want = (xs[0].float() + xs[1].float()).to(torch.bfloat16)
     assert torch.equal(outs[0].cpu(), want) and torch.equal(outs[1].cpu(), want)
     # slabs: each rank's GEMM leaves 4 fp32 partial sums; the all-reduce rounds their sum exactly as the GEMM would
@@ -161,12 +218,11 @@ def test_plain_all_reduce_and_split_k_slabs_as_input():
         with torch.cuda.stream(streams[r]):   # the workspace is per stream, so the two ranks' slabs do not collide
             parts = kernels.gemm(a[r], LinearWeight.dense(wt[r]), split_k=4, partial_out=True)
             got[r], _ = comms[r].all_reduce_add_rms_norm(parts, res.cuda(), nw.cuda(), 1e-6)
-    torch.cuda.synchronize()
+    wait_for_ranks(streams)
     want_out, _ = oracle([y.cpu() for y in ys], res, nw, 1e-6)
     assert torch.equal(got[0], got[1]) and ulp_ok(got[0], want_out)
     assert all(c.error() == 0 for c in comms)
-    for c in comms:
-        c.close()
+    release(comms)
 
 
 def test_bad_arguments_are_rejected():
@@ -261,7 +317,10 @@ def test_lost_peer_fails_the_step():
     set, and the runner's per-step check turns it into an exception instead of returning tokens computed from stale
     staging buffers."""
     from byox_vllm_amd.engine.model_runner import ModelRunner
-    comms = make_world(2, 16, 128)
+    from byox_vllm_amd.layers.comm import XgmiComm
+    comms = [XgmiComm(r, 2, 16, 128) for r in range(2)]      # a world of its own: it ends with the error word set
+    comms[0].set_peer(1, comms[1])
+    comms[1].set_peer(0, comms[0])
     x = torch.ones(4, 128, dtype=torch.bfloat16, device="cuda")
     comms[0].all_reduce(x)                # rank 1 never calls
     torch.cuda.synchronize()
