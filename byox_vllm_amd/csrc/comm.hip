@@ -24,6 +24,7 @@
 // All waits are bounded (about two seconds of the 100 MHz clock); a wait that runs out sets the header's error
 // word and the kernel carries on, so a lost peer cannot hang the GPU.
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -372,7 +373,16 @@ static int allreduce_go(nv_comm* c, const void* x, const float* partials, int nu
   if (rows == 0) return NV_OK;
   int64_t blocks = (rows * (hidden / 8) + 1023) / 1024;
   if (blocks < 8) blocks = 8;
-  if (blocks > 96) blocks = 96;   // every workgroup polls the flags: keep the pollers few and all workgroups resident
+  // Every workgroup polls the flags and waits for its peers' workgroups, so ALL workgroups of ALL ranks that share a
+  // GPU must be resident at once (a GPU holds 512 of them: 2 per CU at this kernel's register count).  One rank per GPU,
+  // the product's configuration, is far inside that with 96.  A rehearsal that puts several ranks on one GPU lowers
+  // the cap through NV_COMM_MAX_BLOCKS (8 ranks x 96 would wait for workgroups that cannot start until a wait times out).
+  static const int max_blocks = [] {
+    const char* e = getenv("NV_COMM_MAX_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 && v <= 96 ? v : 96;
+  }();
+  if (blocks > max_blocks) blocks = max_blocks;
   dim3 grid((unsigned)blocks), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define GO(TT, NN)                                                                                                  \

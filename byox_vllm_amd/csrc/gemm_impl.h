@@ -141,6 +141,18 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
                               : (WFMT == NV_W_DENSE_TILED) ? (uint32_t)(lane * 16)
                               : (WFMT == NV_W_INT8 ? (uint32_t)(lane * 32 + kg * 16) : (uint32_t)(lane * 16 + kg * 8));
   const uint32_t s_lane_off = (uint32_t)(c * 2);
+  // NV_GEMM_WNT=1 (build-time, measurement aid): weight loads carry the non-temporal hint
+#ifndef NV_GEMM_WNT
+#define NV_GEMM_WNT 0
+#endif
+  auto wload4 = [](const char* p) -> u32x4 {
+    if constexpr (NV_GEMM_WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+  };
+  auto wload2 = [](const char* p) -> u32x2 {
+    if constexpr (NV_GEMM_WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    else return *reinterpret_cast<const u32x2*>(p);
+  };
   auto load_w = [&](int kb, uint32_t (&dst)[NTW][WREG], uint16_t (&sdst)[NTW]) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -150,21 +162,21 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
         const char* wp = wb8 + ((int64_t)16 * nt * K + (int64_t)kb * GEMM_BK + 64 * kg) * 2 + w_lane_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 64 * ks);
+          const u32x4 t = wload4(wp + 64 * ks);
           dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
         }
       } else if constexpr (WFMT == NV_W_DENSE_TILED) {   // [N/16][K/128][4 k-steps][64 lanes][8 elements]
         const char* wp = wb8 + (((int64_t)nt * nkb_total + kb) * 4 + 2 * kg) * 1024 + w_lane_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const u32x4 t = *reinterpret_cast<const u32x4*>(wp + 1024 * ks);
+          const u32x4 t = wload4(wp + 1024 * ks);
           dst[j][4 * ks] = t[0]; dst[j][4 * ks + 1] = t[1]; dst[j][4 * ks + 2] = t[2]; dst[j][4 * ks + 3] = t[3];
         }
       } else if constexpr (WFMT == NV_W_INT8) {   // tiled [N/16][K/128][64 lanes][8 dwords]: dwords 4 kg .. 4 kg + 3
-        const u32x4 a = *reinterpret_cast<const u32x4*>(wb8 + ((int64_t)nt * nkb_total + kb) * 2048 + w_lane_off);
+        const u32x4 a = wload4(wb8 + ((int64_t)nt * nkb_total + kb) * 2048 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1]; dst[j][2] = a[2]; dst[j][3] = a[3];
       } else {                                    // tiled [N/16][K/128][64 lanes][4 dwords]: dwords 2 kg, 2 kg + 1
-        const u32x2 a = *reinterpret_cast<const u32x2*>(wb8 + ((int64_t)nt * nkb_total + kb) * 1024 + w_lane_off);
+        const u32x2 a = wload2(wb8 + ((int64_t)nt * nkb_total + kb) * 1024 + w_lane_off);
         dst[j][0] = a[0]; dst[j][1] = a[1];
       }
       if constexpr (!UNQUANTISED)

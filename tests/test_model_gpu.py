@@ -302,6 +302,9 @@ def test_config5_qwen2_7b_tp8_batch512_captured_graph_with_fused_allreduce(monke
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
+    # 8 ranks on ONE GPU: the all-reduce's workgroups wait for their peers' workgroups, so all of them must be resident
+    # together (8 x 32 here; a rank that owns its GPU launches up to 96)
+    monkeypatch.setenv("NV_COMM_MAX_BLOCKS", "32")
     get_rope.cache_clear()
     cfg = SimpleNamespace(vocab_size=1024, hidden_size=3584, intermediate_size=18944, num_hidden_layers=2,
                           num_attention_heads=28, num_key_value_heads=4, head_dim=128, max_position_embeddings=512,
