@@ -62,14 +62,15 @@ struct ChunkRegs {
   uint32_t vv[8][AttnGeom<D>::NM / 2];       // token slot j: NM consecutive d values starting at NM*c
 };
 
-// A cached key/value row is read once per decode step by one wavefront, and a step's rows (every layer's cache) are
-// far more than the caches hold.  With 64-wide heads the loads of the decode walk carry the non-temporal hint, which
-// tells L2 and the Infinity Cache not to keep the lines: 128 sequences x 2 kv heads at context 1024 15.99 -> 14.36 us per
-// launch (8 wavefronts 15.45 -> 14.08), context 4000 5.3 -> 5.7 TB/s.  With 128-wide heads the hint lost 2 % (128 x 4
-// heads: 49.3 -> 50.3 us), so those keep the default policy.  NV_ATTN_NT=0 builds the default-policy form everywhere.
-#ifndef NV_ATTN_NT
-#define NV_ATTN_NT 1
-#endif
+// Non-temporal loads for the decode walk.  A cached key/value row is read once per decode step by one wavefront, and
+// a step's rows (every layer's cache) are usually far more than the caches hold; the hint tells L2 and the Infinity
+// Cache not to keep the lines.  Measured with 64-wide heads: 128 sequences x 2 kv heads at context 1024 15.99 -> 14.36 us
+// per launch (8 wavefronts 15.45 -> 14.08), context 4000 5.3 -> 5.7 TB/s - and, with the LM head streamed the same
+// way, the layer weights of a small model stay resident in the Infinity Cache from step to step (Qwen2-0.5B int4 at
+// batch 128: 1.42 -> 1.355 ms per step; the KV walk alone evicted them every layer).  With 128-wide heads the hint
+// lost 2 % at the kernel (128 x 4 heads: 49.3 -> 50.3 us) and the models that have them do not fit the cache anyway,
+// so those keep the default policy.  A launch whose block tables cannot describe more than a few MB takes the default
+// policy too: a small cache is better re-read from L2 / the Infinity Cache.  NV_ATTN_NT=0 / 1 (environment) forces it.
 template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
@@ -77,13 +78,12 @@ template <bool NT, typename V> __device__ __forceinline__ V stream_load(const V*
 
 // Issue the loads of one chunk.  k_base/v_base point at element [row 0][this kv head][0], row_stride in
 // elements; rows[2] = first row of tile 0 / tile 1 (wave-uniform).  TAIL clamps rows to max_row (packed keys).
-template <typename T, int D, bool TAIL>
+template <typename T, int D, bool TAIL, bool NT = false>
 __device__ __forceinline__ void chunk_load(ChunkRegs<T, D>& r, const uint16_t* k_base, const uint16_t* v_base,
                                            int64_t row_stride, const int64_t (&rows)[2], int64_t max_row) {
   typedef typename VecOf<T>::x8 frag_t;
   constexpr int KS = AttnGeom<D>::KS, NM = AttnGeom<D>::NM;
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  constexpr bool NT = NV_ATTN_NT && D == 64;
   if constexpr (!TAIL) {
     // wave-uniform 64-bit row bases plus one 32-bit per-lane byte offset for K and one for V: the loads take the
     // scalar-base form and the addresses of a whole chunk cost two vector registers instead of two per load
@@ -298,7 +298,7 @@ __device__ __forceinline__ bool ring_round(F& body, std::integer_sequence<int, J
 // ------------------------------------------------------------------ decode
 // NW wavefronts per workgroup share one (sequence, kv head, split); wavefront w takes chunks
 // split*NW + w, + NW*splits, ...  Loads run one chunk ahead of the MFMAs and block-table lookups two ahead.
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool NT>
 __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, const int32_t* __restrict__ block_tables, int bt_stride,
@@ -382,13 +382,13 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
     if (ch < n_chunks) {
       if (ch + step < n_chunks) lookup(ch + step, rows_nxt);
       ChunkRegs<T, D> cur, nxt;
-      chunk_load<T, D, false>(cur, k_base, v_base, row_stride, rows_cur, INT64_MAX);
+      chunk_load<T, D, false, NT>(cur, k_base, v_base, row_stride, rows_cur, INT64_MAX);
       for (; ch < n_chunks; ch += step) {
         const bool has_next = ch + step < n_chunks;
         int64_t rows_nn[2] = {0, 0};
         if (ch + 2 * step < n_chunks) lookup(ch + 2 * step, rows_nn);
         if (has_next) {
-          chunk_load<T, D, false>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
+          chunk_load<T, D, false, NT>(nxt, k_base, v_base, row_stride, rows_nxt, INT64_MAX);
           compute_full(cur, ch);
         } else {
           compute(cur, ch);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
     // unconditionally: a wavefront with fewer chunks than that reads its first chunk again (a cache hit).
     ChunkRegs<T, D> rs[DEPTH];
     int64_t rw[2];
-    chunk_load<T, D, false>(rs[0], k_base, v_base, row_stride, rows0, INT64_MAX);
+    chunk_load<T, D, false, NT>(rs[0], k_base, v_base, row_stride, rows0, INT64_MAX);
 #pragma unroll
     for (int j = 1; j < DEPTH - 1; ++j) {
       int64_t rj[2];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
       const bool exists = ch + j * step < n_chunks;
       rj[0] = exists ? rj[0] : rows0[0];
       rj[1] = exists ? rj[1] : rows0[1];
-      chunk_load<T, D, false>(rs[j], k_base, v_base, row_stride, rj, INT64_MAX);
+      chunk_load<T, D, false, NT>(rs[j], k_base, v_base, row_stride, rj, INT64_MAX);
     }
     lookup(ch + (DEPTH - 1) * step, rw);   // rows of the next chunk to load (used only if that chunk exists)
     // body J: multiply set J, refill the set that was multiplied last (J - 1) with the chunk DEPTH - 1 ahead; returns
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
       }
       int64_t rn[2];
       lookup(ch + DEPTH * step, rn);
-      chunk_load<T, D, false>(rs[(J + DEPTH - 1) % DEPTH], k_base, v_base, row_stride, rw, INT64_MAX);
+      chunk_load<T, D, false, NT>(rs[(J + DEPTH - 1) % DEPTH], k_base, v_base, row_stride, rw, INT64_MAX);
       compute_full(rs[J], ch);
       ch += step;
       rw[0] = rn[0];
@@ -1049,7 +1049,7 @@ static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
 
 // Revision of paged_decode_kernel's memory access pattern.  Bumped with every change that can alter the bytes a launch
 // moves; counter collections name the revision they were taken on, so a stale one is recognised.
-#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03a"
+#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03b"
 extern "C" const char* nv_paged_attn_decode_kernel_tag(void) { return NV_PAGED_DECODE_KERNEL_TAG; }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
@@ -1097,10 +1097,17 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
   dim3 block(256);
   const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits, (int64_t)bt_stride * block_size);
   dim3 grid(num_splits, Hkv, B);
-#define LAUNCH_DEC(TT, DD, WW)                                                                                       \
-  paged_decode_kernel<TT, DD, WW><<<grid, dim3(WW * 64), 0, s>>>(                                                    \
+  // non-temporal K/V loads: 64-wide heads, and a cache region behind this launch's block tables of at least 8 MB
+  bool nt = D == 64 && (int64_t)B * Hkv * bt_stride * block_size * D * 4 >= ((int64_t)8 << 20);
+  if (const char* e = getenv("NV_ATTN_NT")) nt = D == 64 && atoi(e) == 1;
+#define LAUNCH_DEC_ARGS                                                                                              \
       (const uint16_t*)q, q_row_stride, (const uint16_t*)k_cache, (const uint16_t*)v_cache, block_tables, bt_stride, \
-      context_lens, (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv, block_size, scale2, num_splits)
+      context_lens, (uint16_t*)out, out_row_stride, part_o, part_ml, H, Hkv, block_size, scale2, num_splits
+#define LAUNCH_DEC(TT, DD, WW)                                                                         \
+  do {                                                                                                 \
+    if (DD == 64 && nt) paged_decode_kernel<TT, DD, WW, DD == 64><<<grid, dim3(WW * 64), 0, s>>>(LAUNCH_DEC_ARGS); \
+    else paged_decode_kernel<TT, DD, WW, false><<<grid, dim3(WW * 64), 0, s>>>(LAUNCH_DEC_ARGS);       \
+  } while (0)
 #define LAUNCH_DEC_T(TT)                                                         \
   do {                                                                           \
     if (D == 128) {                                                              \
@@ -1118,6 +1125,7 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
   if (dtype == NV_BF16) LAUNCH_DEC_T(bf16_t); else LAUNCH_DEC_T(f16_t);
 #undef LAUNCH_DEC_T
 #undef LAUNCH_DEC
+#undef LAUNCH_DEC_ARGS
   NV_CHECK_LAUNCH();
   if (num_splits > 1) {
     const int64_t total = (int64_t)B * H;

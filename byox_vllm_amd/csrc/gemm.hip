@@ -39,6 +39,7 @@ struct GemmArgs {
   SampleParts stats;   // epi == 4 only
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
+  int stream_once; // 1: non-temporal weight loads and result stores (streaming-layout weights, epi 0 / 4, one row tile)
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);
@@ -85,6 +86,17 @@ static double plan_cost(int64_t M, int N, int K, int wfmt, int ntw, int split_k,
   if (slabs) us += 2.0 * split_k * (double)M * N * 4.0 / 4.0e6;   // slab bytes at ~4 TB/s, written and read once
   if (slabs && split_k > 8) us += 1.0;   // the consumer sums slabs in batches of 8 loads: a ninth costs it a round trip
   return us;
+}
+
+// 1 where a launch reads a streaming-layout (unquantised) matrix of at least 64 MB exactly once - a single row
+// tile, no K split: the LM head of a decode step.  Its loads and result stores then carry the non-temporal hint
+// (gemm_body, STREAM), leaving the Infinity Cache to the layer weights.  With several row tiles (a prefill's LM
+// head) the tiles re-read the weights from the caches, which the hint would defeat.  NV_GEMM_STREAM=0 / 1 forces it.
+static int plan_stream_once(const GemmArgs& a) {
+  if (a.wfmt != NV_W_DENSE_TILED || a.split_k != 1 || (a.epi != 0 && a.epi != 4)) return 0;
+  int on = a.M <= a.bm && (int64_t)a.N * a.K * 2 >= ((int64_t)64 << 20);
+  if (const char* e = getenv("NV_GEMM_STREAM")) on = atoi(e) == 1;
+  return on;
 }
 
 // Tiles per wavefront for a given split: dense weights take 1 or 2 (16 raw registers per tile), quantised 1 to 3.
@@ -189,6 +201,7 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
     if (a.mixed) a.bm = 128;
   }
   if (a.mixed) a.wide = 0;
+  a.stream_once = plan_stream_once(a);
   if (a.wide) {
     if (dtype == NV_BF16) nv_gemm_wide_launch_bf16(a); else nv_gemm_wide_launch_f16(a);
   } else {
@@ -247,6 +260,7 @@ extern "C" int nv_lm_head_sample(const void* x, int64_t x_row_stride, const void
   a.stats.s = a.stats.m + M * a.stats.P;
   a.stats.temps = temperatures;
   a.stream = (hipStream_t)stream;
+  a.stream_once = plan_stream_once(a);
   if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
   NV_CHECK_LAUNCH();
   return nv_sample_pick_launch(logits, logits_row_stride, temperatures, tokens, workspace, (int)M, V, seed, seed_offset,
@@ -321,6 +335,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   GemmArgs a;
   a.wide = 0;
   a.mixed = 0;
+  a.stream_once = 0;
   a.stats = SampleParts{};
   a.x = x; a.xs = x_row_stride; a.w = w; a.scales = scales; a.bias = bias; a.out = qkv; a.os = qkv_row_stride;
   a.partial = nullptr; a.M = M; a.N = N; a.K = K; a.split_k = 1; a.wfmt = wfmt;

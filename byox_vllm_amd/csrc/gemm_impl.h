@@ -67,7 +67,13 @@ constexpr int gemm_lds_bytes() {
 // The work of one wavefront of a 512-thread workgroup: column group `wid` (0..3) of k-step group `kg` (0..1), NTW
 // tiles starting at tile nt0.  The caller owns the LDS block and decides which wavefront is which; all wavefronts of
 // a workgroup must run the same BM and EPI (they meet at the same barriers) but may differ in NTW.
-template <typename T, int WFMT, int BM, int NTW, int EPI>   // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
+// STREAM (epilogues 0 and 4): the weight matrix is far larger than the caches and every byte of it is read once per
+// launch by one wavefront (the LM head in a decode step), so its loads and the stores of the result carry the
+// non-temporal hint: they do not displace what the rest of the step keeps in the Infinity Cache.  Measured on the
+// metric configuration (Qwen2-0.5B int4, 128 rows): with the KV walk and the LM head both non-temporal the 179 MB of
+// layer weights stay cache-resident from step to step, 1.42-1.44 -> 1.355 ms per step; either one alone gains nothing.
+template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false>
+                                                            // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
                                                             //      4 = store + the sampler's per-part statistics (LM head)
 __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_t x_stride,
@@ -141,16 +147,17 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
                               : (WFMT == NV_W_DENSE_TILED) ? (uint32_t)(lane * 16)
                               : (WFMT == NV_W_INT8 ? (uint32_t)(lane * 32 + kg * 16) : (uint32_t)(lane * 16 + kg * 8));
   const uint32_t s_lane_off = (uint32_t)(c * 2);
-  // NV_GEMM_WNT=1 (build-time, measurement aid): weight loads carry the non-temporal hint
+  // NV_GEMM_WNT=1 (build-time, measurement aid): every weight load carries the non-temporal hint
 #ifndef NV_GEMM_WNT
 #define NV_GEMM_WNT 0
 #endif
+  constexpr bool WNT = STREAM || NV_GEMM_WNT == 1;
   auto wload4 = [](const char* p) -> u32x4 {
-    if constexpr (NV_GEMM_WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    if constexpr (WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     else return *reinterpret_cast<const u32x4*>(p);
   };
   auto wload2 = [](const char* p) -> u32x2 {
-    if constexpr (NV_GEMM_WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    if constexpr (WNT) return __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
     else return *reinterpret_cast<const u32x2*>(p);
   };
   auto load_w = [&](int kb, uint32_t (&dst)[NTW][WREG], uint16_t (&sdst)[NTW]) {
@@ -447,7 +454,10 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
         o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
         o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
 #ifndef NV_ABL_NOSTORE
-        if (m < M && tile_live) *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+        if (m < M && tile_live) {
+          if constexpr (STREAM) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(out + m * out_stride + nb));
+          else *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+        }
 #endif
         float v[4] = {lo_f32<T>(o[0]), hi_f32<T>(o[0]), lo_f32<T>(o[1]), hi_f32<T>(o[1])};
         if (!tile_live) v[0] = v[1] = v[2] = v[3] = -INFINITY;
@@ -504,7 +514,10 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
 #ifdef NV_ABL_NOSTORE
           if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)   // keeps the arithmetic alive, practically never stores
 #endif
-          *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+          {
+            if constexpr (STREAM) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(out + m * out_stride + nb));
+            else *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
+          }
         }
       }
     } else if constexpr (EPI == 1) {
@@ -553,7 +566,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
 // A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
 // two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
 // dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
-template <typename T, int WFMT, int BM, int NTW, int EPI>
+template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false>
 __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                    const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
@@ -562,8 +575,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[gemm_lds_bytes<BM, NTW, EPI>()];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = wave & 3, kg = wave >> 2;         // column group of 4 wavefronts, k-step group
-  gemm_body<T, WFMT, BM, NTW, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, ra, sp,
-                                   lds_raw, wid, kg, (blockIdx.x * 4 + wid) * NTW);
+  gemm_body<T, WFMT, BM, NTW, EPI, STREAM>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, ra,
+                                           sp, lds_raw, wid, kg, (blockIdx.x * 4 + wid) * NTW);
 }
 
 // 128 rows x 160 columns per workgroup: column groups 0 and 1 take three tiles per wavefront, groups 2 and 3 two.
@@ -623,13 +636,14 @@ struct GemmArgs {
   SampleParts stats;   // epi == 4 only
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
+  int stream_once; // 1: non-temporal weight loads and result stores (streaming-layout weights, epi 0 / 4, one row tile)
 };
 #endif
 
-template <typename T, int WFMT, int NTW, int EPI>
+template <typename T, int WFMT, int NTW, int EPI, bool STREAM = false>
 static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 #define GO(BMV)                                                                                               \
-  gemm_kernel<T, WFMT, BMV, NTW, EPI><<<grid, dim3(512), 0, a.stream>>>(                                      \
+  gemm_kernel<T, WFMT, BMV, NTW, EPI, STREAM><<<grid, dim3(512), 0, a.stream>>>(                              \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,  \
       a.os, a.partial, a.M, a.N, a.K, a.split_k, a.rope, a.stats)
   switch (a.bm) {
@@ -676,6 +690,9 @@ static void gemm_dispatch(const GemmArgs& a) {
   dim3 grid((ntiles + per_block - 1) / per_block, (unsigned)((a.M + a.bm - 1) / a.bm), a.split_k);
   if (a.wfmt == NV_W_DENSE) {
     if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2>(a, grid);
+  } else if (a.wfmt == NV_W_DENSE_TILED && a.stream_once && (a.epi == 0 || a.epi == 4)) {
+    if (a.epi == 4) { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 4, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 4, true>(a, grid); }
+    else            { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 0, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 0, true>(a, grid); }
   } else if (a.wfmt == NV_W_DENSE_TILED) {
     if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE_TILED, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE_TILED, 2>(a, grid);
   } else if (a.wfmt == NV_W_INT8) {

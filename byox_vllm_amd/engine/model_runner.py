@@ -50,6 +50,7 @@ class ModelRunner:
             and not self.use_xgmi)
         self.world_size = config.tensor_parallel_size
         self.device_bookkeeping = os.environ.get("NV_DEVICE_BOOKKEEPING", "1") != "0"
+        self.spin_wait = os.environ.get("NV_SPIN_WAIT", "1") != "0"
         self.rank = rank
         self.event = event
         if not torch.cuda.is_available():
@@ -251,10 +252,24 @@ class ModelRunner:
             ntok = cache["ntok"].tolist()
         g["padded_bs"] = padded
         self._replay(padded)
-        torch.cuda.current_stream().synchronize()
+        self._wait_for_step()
         tokens = self._host_tokens_np[:bs].tolist()
         cache["padded"], cache["tokens"], cache["next_ntok"] = padded, tokens, [x + 1 for x in ntok]
         return tokens
+
+    def _wait_for_step(self) -> None:
+        """Block until the replayed graph (which ends by delivering the tokens to pinned host memory) has finished.
+        The step is synchronous by contract - the scheduler needs this step's tokens before it can form the next -
+        so the GPU idles from the graph's end until the host has noticed and launched again.  Polling the stream
+        (hipStreamQuery, about a microsecond per call) notices within microseconds; a blocking synchronize sleeps on an
+        interrupt and wakes up tens of microseconds later.  NV_SPIN_WAIT=0 restores the blocking wait."""
+        stream = torch.cuda.current_stream()
+        if self.spin_wait:
+            query = stream.query
+            while not query():
+                pass
+        else:
+            stream.synchronize()
 
     def _continues_previous_step(self, seqs: list[Sequence], padded: int):
         """The sequences' lengths when this decode step is the previous graph step continued: the same Sequence objects

@@ -187,11 +187,15 @@ def test_paged_decode_attention(name, cfg, splits):
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8", "16"])
 @pytest.mark.parametrize("cfg", [PAGED_CASES[0], PAGED_CASES[2], PAGED_CASES[5], PAGED_CASES[6], PAGED_CASES[7]])
 @pytest.mark.parametrize("splits", [1, 3])
-def test_paged_decode_forced_wavefront_counts(cfg, waves, splits, monkeypatch):
+@pytest.mark.parametrize("hint", ["0", "1"])
+def test_paged_decode_forced_wavefront_counts(cfg, waves, splits, hint, monkeypatch):
     """Every compiled workgroup size of the decode kernel (1, 2, 4, 8, 16 wavefronts; 16 exists at D=64 only and
-    falls back to 8 at D=128) is the same function.  Without the override the launch shape picks among 2, 4 and 8."""
+    falls back to 8 at D=128) is the same function, with default-policy and with non-temporal K/V loads (the form
+    launches over large caches of 64-wide heads take; NV_ATTN_NT forces either).  Without the overrides the launch
+    shape picks among 2, 4 and 8 wavefronts."""
     from byox_vllm_amd import kernels
     monkeypatch.setenv("NV_ATTN_WAVES", waves)
+    monkeypatch.setenv("NV_ATTN_NT", hint)
     q, kc, vc, ctx, tables = _paged_case(dt=torch.bfloat16, **cfg)
     want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
     got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5,
