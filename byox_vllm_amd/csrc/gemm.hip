@@ -39,7 +39,7 @@ struct GemmArgs {
   SampleParts stats;   // epi == 4 only
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
-  int stream_once; // 1: non-temporal weight loads and result stores (streaming-layout weights, epi 0 / 4, one row tile)
+  int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);
@@ -89,8 +89,8 @@ static double plan_cost(int64_t M, int N, int K, int wfmt, int ntw, int split_k,
 }
 
 // 1 where a launch reads a streaming-layout (unquantised) matrix of at least 64 MB exactly once - a single row
-// tile, no K split: the LM head of a decode step.  Its loads and result stores then carry the non-temporal hint
-// (gemm_body, STREAM), leaving the Infinity Cache to the layer weights.  With several row tiles (a prefill's LM
+// tile, no K split: the LM head of a decode step.  Its weight loads then carry the non-temporal hint (gemm_body,
+// STREAM), leaving the Infinity Cache to the layer weights.  With several row tiles (a prefill's LM
 // head) the tiles re-read the weights from the caches, which the hint would defeat.  NV_GEMM_STREAM=0 / 1 forces it.
 static int plan_stream_once(const GemmArgs& a) {
   if (a.wfmt != NV_W_DENSE_TILED || a.split_k != 1 || (a.epi != 0 && a.epi != 4)) return 0;

@@ -68,10 +68,13 @@ constexpr int gemm_lds_bytes() {
 // tiles starting at tile nt0.  The caller owns the LDS block and decides which wavefront is which; all wavefronts of
 // a workgroup must run the same BM and EPI (they meet at the same barriers) but may differ in NTW.
 // STREAM (epilogues 0 and 4): the weight matrix is far larger than the caches and every byte of it is read once per
-// launch by one wavefront (the LM head in a decode step), so its loads and the stores of the result carry the
-// non-temporal hint: they do not displace what the rest of the step keeps in the Infinity Cache.  Measured on the
-// metric configuration (Qwen2-0.5B int4, 128 rows): with the KV walk and the LM head both non-temporal the 179 MB of
-// layer weights stay cache-resident from step to step, 1.42-1.44 -> 1.355 ms per step; either one alone gains nothing.
+// launch by one wavefront (the LM head in a decode step), so its loads carry the non-temporal hint: they do not
+// displace what the rest of the step keeps in the Infinity Cache.  Measured on the metric configuration (Qwen2-0.5B
+// int4, 128 rows): with the KV walk and the LM head both non-temporal the 179 MB of layer weights stay cache-resident
+// from step to step, 1.42-1.44 -> 1.355 ms per step (o/down 6.5 -> 6.0, gate_up 9.9 -> 9.3, q/k/v 7.6 -> 6.9 us per
+// launch); either one alone gains nothing.  The logits are stored with the default policy: non-temporal 8-byte
+// stores of four lanes per row took the launch from 92 to 110 us (no write combining), 6 us per step more than the
+// 39 MB of cache the logits buffer occupies cost.
 template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false>
                                                             // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
@@ -454,10 +457,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
         o[0] = pack2<T>(acc[j][i][0] + b4[0], acc[j][i][1] + b4[1]);
         o[1] = pack2<T>(acc[j][i][2] + b4[2], acc[j][i][3] + b4[3]);
 #ifndef NV_ABL_NOSTORE
-        if (m < M && tile_live) {
-          if constexpr (STREAM) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(out + m * out_stride + nb));
-          else *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
-        }
+        if (m < M && tile_live) *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
 #endif
         float v[4] = {lo_f32<T>(o[0]), hi_f32<T>(o[0]), lo_f32<T>(o[1]), hi_f32<T>(o[1])};
         if (!tile_live) v[0] = v[1] = v[2] = v[3] = -INFINITY;
@@ -514,10 +514,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
 #ifdef NV_ABL_NOSTORE
           if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)   // keeps the arithmetic alive, practically never stores
 #endif
-          {
-            if constexpr (STREAM) __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(out + m * out_stride + nb));
-            else *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
-          }
+          *reinterpret_cast<u32x2*>(out + m * out_stride + nb) = o;
         }
       }
     } else if constexpr (EPI == 1) {
@@ -636,7 +633,7 @@ struct GemmArgs {
   SampleParts stats;   // epi == 4 only
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
-  int stream_once; // 1: non-temporal weight loads and result stores (streaming-layout weights, epi 0 / 4, one row tile)
+  int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
 };
 #endif
 

@@ -92,6 +92,12 @@ def test_whole_model_vs_reference_goldens(golden, style, dname):
         assert e_hip.max().item() <= ERROR_RATIO * e_ref.max().item(), report[-1]
         assert e_hip.pow(2).mean().sqrt().item() <= ERROR_RATIO * e_ref.pow(2).mean().sqrt().item(), report[-1]
         assert (logits - ref).abs().max().item() < (LOGIT_TOL if dname == "bf16" else LOGIT_TOL / 8), name
+        if dname == "fp16":
+            # the plain distance between the two 16-bit paths, at the precision of the reference's own CPU-runnable
+            # configuration (fp16): within 1e-3 of the reference's logits, i.e. within one fp16 ulp (2^-10) at these
+            # magnitudes (measured 0.0005-0.0010); bf16 logits of this size are spaced 0.004-0.008 apart, there the
+            # two paths differ by one such step (measured 0.0039-0.0078) and the ratio rule above is the bar
+            assert (logits - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()), name
         if name == "prefill":
             assert logits.argmax(-1).tolist() == ref.argmax(-1).tolist()
     for row in report:
