@@ -22,7 +22,11 @@ implementation (`--allreduce rccl` is the headline, the peer-memory all-reduce
 fused with add+RMSNorm is reported as `xgmi_allreduce_tok_s`, or the other way
 round) and N independent replicas of the single-GPU step (no data-path
 collective, `replicas_tok_s`); `--parallelism dp` makes the replicas the
-headline instead.
+headline instead.  The replicas are timed FIRST and their line is handed to a
+small keeper process: should a tensor-parallel leg then take the ranks down
+(a GPU fault aborts the process, no exception to catch) or stall past
+NV_BENCH_LEG_DEADLINE seconds, the keeper prints that line, marked as such in
+`tp_error`, so a lease of a multi-GPU node always yields a measurement.
 """
 
 import argparse
@@ -178,7 +182,7 @@ def cpu_baseline(model_name, quantization, dtype, batch, context, budget_s=20.0,
         kv[:, :, 1:] = kv[:, :, :1]
     tables = [list(range(i * blocks_per_seq, (i + 1) * blocks_per_seq)) for i in range(batch)]
     lens = [context] * batch
-    ids = torch.randint(0, 10000, (batch,))
+    ids = torch.randint(0, min(10000, hf.vocab_size), (batch,))
     setup = time.perf_counter() - t0
     steps, t_layers, t_head = 0, 0.0, 0.0
     while steps < 1 or (t_layers + t_head < budget_s / 2 and steps < 4):
@@ -278,6 +282,55 @@ def run_generate_workload(args):
     print(json.dumps(line), flush=True)
 
 
+KEEPER = r"""
+import os, select, signal, sys
+deadline = float(sys.argv[1]); parent = int(sys.argv[2])
+line, buf = None, b""
+while True:
+    ready, _, _ = select.select([0], [], [], deadline if line is not None else None)
+    if not ready:                                   # a leg stalled after the provisional line arrived
+        try:
+            os.kill(parent, signal.SIGKILL)
+        except OSError:
+            pass
+        break
+    chunk = os.read(0, 1 << 16)
+    if not chunk:                                   # the writer is gone
+        break
+    buf += chunk
+    while b"\n" in buf:
+        ln, buf = buf.split(b"\n", 1)
+        if ln == b"DONE":
+            sys.exit(0)
+        line = ln
+if line is not None:
+    sys.stdout.buffer.write(line + b"\n"); sys.stdout.flush()
+"""
+
+
+class LineKeeper:
+    """Rank 0 of a multi-rank job: a child process (started before this process touches the GPU) that holds the last
+    complete JSON line it was given and prints it if this process ends without saying DONE, or goes quiet for longer
+    than NV_BENCH_LEG_DEADLINE seconds (default 900; the keeper then also ends this process, so that only one line
+    is ever printed).  The tensor-parallel legs have never run on more than one device; a fault there aborts the
+    process from a runtime thread, where no Python handler gets a turn."""
+
+    def __init__(self):
+        import subprocess
+        deadline = os.environ.get("NV_BENCH_LEG_DEADLINE", "900")
+        self.proc = subprocess.Popen([sys.executable, "-c", KEEPER, deadline, str(os.getpid())], stdin=subprocess.PIPE)
+
+    def hold(self, line: dict):
+        self.proc.stdin.write((json.dumps(line) + "\n").encode())
+        self.proc.stdin.flush()
+
+    def done(self):
+        self.proc.stdin.write(b"DONE\n")
+        self.proc.stdin.flush()
+        self.proc.stdin.close()
+        self.proc.wait()
+
+
 def self_launch(gpus: int, argv: list[str]) -> int:
     """`python bench.py --gpus N` started plainly: run the N ranks under torch.distributed.run as a CHILD process (this
     process has not touched a GPU and never will), pass the child's output through and return its exit code.  The
@@ -323,6 +376,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    keeper = LineKeeper() if (world > 1 and rank == 0) else None      # started before this process touches a GPU
     # NV_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("NV_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -425,6 +479,10 @@ def main():
         try:
             if tp_size > 1 and os.environ.get("NV_BENCH_FAIL_TP"):      # test hook: exercises the fallback below
                 raise RuntimeError("tensor-parallel leg failed on request (NV_BENCH_FAIL_TP)")
+            if tp_size > 1 and os.environ.get("NV_BENCH_ABORT_TP"):     # test hook: the process dies as under a GPU fault
+                os.abort()
+            if tp_size > 1 and os.environ.get("NV_BENCH_STALL_TP"):     # test hook: a leg that never comes back
+                time.sleep(1e6)
             runner, seqs, driver = build(tp_size, allreduce)
             elapsed = timed(driver)
         except Exception as e:
@@ -448,43 +506,30 @@ def main():
         from byox_vllm_amd.layers.rotary_embedding import get_rope
         get_rope.cache_clear()
 
-    tp_error = None
-    runner, seqs, elapsed, error = leg(tp, args.allreduce)
-    if runner is None:
-        # A tensor-parallel step that fails on this stack must not cost the whole measurement: fall back to one
-        # replica per rank, say so.
-        if tp == 1:
-            raise RuntimeError(error)
-        tp_error = error
-        print(f"[bench] rank {rank}: the tensor-parallel leg failed ({tp_error}); measuring {world} replicas instead",
-              file=sys.stderr, flush=True)
-        tp = 1
-        runner, seqs, elapsed, error = leg(1)
-        if runner is None:
-            raise RuntimeError(error)
-
-    replicas = world // tp
-    tokens = batch * args.steps * replicas
-    bytes_step = step_bytes(runner, seqs, hf, tp)
-    kern_s, launches = time_attention_kernel(runner, seqs)
-    kv_bytes = kv_bytes_per_launch(seqs, hf, tp)
-    achieved = kv_bytes / kern_s / 1e9
-    traffic, traffic_source = pmc_traffic(kv_bytes, hf.head_dim, max(1, hf.num_key_value_heads // tp))
-    graph_captured = not runner.enforce_eager
-    uses_comm = runner.comm is not None
-
-    if rank == 0:
-        line = {
+    def make_line(runner, seqs, elapsed, tp_now, tp_error):
+        """The JSON line of one timed leg (a dict on rank 0, None elsewhere); every rank times the attention launch."""
+        replicas = world // tp_now
+        tokens = batch * args.steps * replicas
+        bytes_step = step_bytes(runner, seqs, hf, tp_now)
+        kern_s, launches = time_attention_kernel(runner, seqs)
+        kv_bytes = kv_bytes_per_launch(seqs, hf, tp_now)
+        achieved = kv_bytes / kern_s / 1e9
+        traffic, traffic_source = pmc_traffic(kv_bytes, hf.head_dim, max(1, hf.num_key_value_heads // tp_now))
+        graph_captured = not runner.enforce_eager
+        uses_comm = runner.comm is not None
+        if rank != 0:
+            return None
+        return {
             "metric": "decode tokens/s",
             "value": round(tokens / elapsed, 1),
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if tp_now == 1 else "strong", "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic (random weights, random KV history, random prompts)",
             "config": {"workload": args.workload, "geometry": model_name, "weight_format": quantization or dtype_name,
                        "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
-                       "parallelism": f"{'tp' if tp > 1 else 'dp'}{world}", "graph": graph_captured,
+                       "parallelism": f"{'tp' if tp_now > 1 else 'dp'}{world}", "graph": graph_captured,
                        "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
             "ranks": world,
             # ranks that talk through RCCL: 0 when the job's process group is a rehearsal backend or there is one rank
@@ -492,7 +537,7 @@ def main():
             "backend": (("rccl" if backend == "nccl" else backend) if world > 1 else None),
             "graph_captured": graph_captured,
             "allreduce": (("nv_allreduce_add_rmsnorm (peer-mapped memory)" if uses_comm else
-                           "torch.distributed all_reduce") if tp > 1 else None),
+                           "torch.distributed all_reduce") if tp_now > 1 else None),
             "tp_error": tp_error,
             "step_hbm_fraction": round(bytes_step / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "step_algorithmic_bytes": bytes_step,
@@ -501,14 +546,53 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": kv_bytes, "avg_launch_us": round(kern_s * 1e6, 2), "launches_timed": launches},
         }
-        if world == 1 and not args.no_cpu_baseline:
+
+    # N independent replicas of the single-GPU step, no collective on the data path: what the hardware does with this
+    # workload when nothing is exchanged.  Under tensor parallelism it is timed first: it is the leg that cannot fail
+    # in a new way on a multi-GPU node, and the keeper process holds its line from here on.
+    replicas_line, have_replicas = None, False
+    if tp > 1 and not args.no_replicas:
+        r0, s0, e0, err0 = leg(1)
+        have_replicas = r0 is not None        # the ranks agree on this (leg)
+        if have_replicas:
+            replicas_line = make_line(r0, s0, e0, 1, "the job ended or stalled during the tensor-parallel legs; this is "
+                                                    "the line of the replicas leg, printed by the keeper process")
+            release(r0)
+            if keeper is not None:
+                keeper.hold(replicas_line)
+        del r0
+
+    tp_error = None
+    runner, seqs, elapsed, error = leg(tp, args.allreduce)
+    if runner is None:
+        # A tensor-parallel step that fails on this stack must not cost the whole measurement: fall back to one
+        # replica per rank, say so.
+        if tp == 1:
+            raise RuntimeError(error)
+        tp_error = error
+        print(f"[bench] rank {rank}: the tensor-parallel leg failed ({tp_error}); reporting {world} replicas instead",
+              file=sys.stderr, flush=True)
+        tp = 1
+        if not have_replicas:
+            runner, seqs, elapsed, error = leg(1)
+            if runner is None:
+                raise RuntimeError(error)
+
+    if runner is not None:
+        line = make_line(runner, seqs, elapsed, tp, tp_error)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model_name, quantization, DTYPES[dtype_name], batch, context)
-    release(runner)
+        release(runner)
+    elif rank == 0:
+        # the replicas were timed above: theirs is the measurement, with the tensor-parallel leg's error in it
+        line = dict(replicas_line, tp_error=tp_error)
     del runner
     if tp > 1 and not args.single_leg:
         # the same tensor-parallel job with the other all-reduce, so that one lease of a multi-GPU node compares them
         other = "xgmi" if args.allreduce == "rccl" else "rccl"
         key = "xgmi_allreduce_tok_s" if other == "xgmi" else "rccl_allreduce_tok_s"
+        if keeper is not None:   # from here on a crash costs only the comparison
+            keeper.hold(dict(line, **{key.replace("tok_s", "error"): "the job ended or stalled during this leg"}))
         r2, _, e2, err2 = leg(tp, other)
         if rank == 0:
             line[key] = round(batch * args.steps / e2, 1) if r2 is not None else None
@@ -519,16 +603,12 @@ def main():
         if r2 is not None:
             release(r2)
         del r2
-    if tp > 1 and not args.no_replicas:
-        # the same job as N independent replicas of the single-GPU step: what the hardware does with this workload
-        # when no collective sits on the critical path (every rank takes part: the timing has barriers)
-        r3, _, e3, err3 = leg(1)
-        if rank == 0:
-            line["replicas_tok_s"] = round(batch * args.steps * world / e3, 1) if r3 is not None else None
-        if r3 is not None:
-            release(r3)
     if rank == 0:
+        if tp > 1 and not args.no_replicas:
+            line["replicas_tok_s"] = replicas_line["value"] if replicas_line is not None else None
         print(json.dumps(line), flush=True)
+        if keeper is not None:
+            keeper.done()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,3 +29,28 @@ def test_cpu_baseline_samples_layers_of_the_7b_geometry():
 def test_default_workload_is_the_metric_configuration():
     model, quant, dtype, batch, context = bench.WORKLOADS[bench.DEFAULT_WORKLOAD]
     assert (model, quant, dtype, batch, context) == ("qwen2-0.5b", "w4a16", "bf16", 128, 1024)
+
+
+def _keeper_parent(body, deadline="30"):
+    """A stand-in for rank 0: a process that starts the keeper, hands it lines and then runs ``body``."""
+    import subprocess
+    code = ("import sys, time, os; sys.path.insert(0, %r); import bench; k = bench.LineKeeper(); "
+            "k.hold({'value': 1}); k.hold({'value': 2}); " % ROOT) + body
+    return subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NV_BENCH_LEG_DEADLINE=deadline),
+                          capture_output=True, text=True, timeout=120)
+
+
+def test_keeper_stays_silent_when_the_job_finishes():
+    out = _keeper_parent("print('final', flush=True); k.done()")
+    assert out.returncode == 0 and out.stdout.strip() == "final"
+
+
+def test_keeper_prints_the_last_held_line_when_the_job_dies():
+    """os.abort() is what a GPU fault does to the process: no exception, no atexit."""
+    out = _keeper_parent("os.abort()")
+    assert out.returncode != 0 and out.stdout.strip() == '{"value": 2}'
+
+
+def test_keeper_ends_a_stalled_job_and_prints_the_line():
+    out = _keeper_parent("time.sleep(100)", deadline="2")
+    assert out.returncode == -9 and out.stdout.strip() == '{"value": 2}'

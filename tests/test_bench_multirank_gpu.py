@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra, env_extra=None, launcher=False):
+def _bench(extra, env_extra=None, launcher=False, expect_failure=False):
     env = dict(os.environ, NV_BENCH_BACKEND="gloo", NV_DIST_BACKEND="gloo", **(env_extra or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
@@ -25,7 +25,7 @@ def _bench(extra, env_extra=None, launcher=False):
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
             "--workload", "qwen2-0.5b-fp16-b1-s128"] + extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert (out.returncode != 0) == expect_failure, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]          # exactly one line, from rank 0
     return json.loads(lines[0])
@@ -47,6 +47,7 @@ def test_bench_two_ranks(mode):
     captured = mode in ("dp", "xgmi")
     assert d["graph_captured"] == captured and d["config"]["graph"] == captured
     assert ("replicas_tok_s" in d) == (mode != "dp") and d.get("replicas_tok_s", 1) > 0
+    assert d["tp_error"] is None
     if mode == "default":
         assert d["allreduce"].startswith("torch.distributed")
         assert d["xgmi_allreduce_tok_s"] > 0 and d["xgmi_allreduce_graph_captured"] is True
@@ -65,3 +66,13 @@ def test_bench_falls_back_to_replicas_when_the_tensor_parallel_leg_fails():
     d = _bench([], env_extra={"NV_BENCH_FAIL_TP": "1"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert "NV_BENCH_FAIL_TP" in d["tp_error"] and "replicas_tok_s" not in d
+
+
+@pytest.mark.parametrize("hook", ["NV_BENCH_ABORT_TP", "NV_BENCH_STALL_TP"])
+def test_bench_line_survives_a_tensor_parallel_leg_that_takes_the_job_down(hook):
+    """A GPU fault aborts the process from a runtime thread and a lost peer can stall a collective for good: neither
+    is an exception.  The replicas leg has been timed by then and the keeper process started by rank 0 prints its
+    line — exactly one line, marked in `tp_error` — while the job itself ends with a failure status."""
+    d = _bench([], env_extra={hook: "1", "NV_BENCH_LEG_DEADLINE": "20"}, expect_failure=True)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert "keeper process" in d["tp_error"] and d["roofline"]["frac"] > 0
