@@ -32,6 +32,8 @@ _PROTOS = {
     "nv_paged_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "nv_paged_attn_decode_pick_splits": (_i, [_i, _i, _i]),
     "nv_paged_attn_decode_kernel_tag": (C.c_char_p, []),
+    "nv_set_result_policy": (_i, [_i]),
+    "nv_get_result_policy": (_i, []),
     "nv_paged_attn_decode": (_i, [_p, _i64, _p, _p, _p, _i, _p, _p, _i64, _p, _sz, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "nv_paged_attn_decode_static": (_i, [_p, _i64, _p, _p, _p, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "nv_attn_prefill": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p]),

@@ -11,6 +11,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Store of a kernel's result that the next launch of a chain reads.  NT = non-temporal: the line does not take room
+// in the memory-side cache that a small model's weights can otherwise keep from one decode step to the next.  The
+// choice is a template parameter of the kernels, made by their launchers from the process-wide result-store policy
+// (nv_set_result_policy): written as a run-time branch around the store it costs more than it gains (the compiler
+// merges `if (nt) nontemporal_store else store` into one plain store, and an inline-asm store in its place slowed the
+// step with the policy off by as much as the policy gains).
+template <bool NT, typename V>
+__device__ __forceinline__ void out_store(V* p, V v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+int nv_result_policy();   // 1: results are stored non-temporal (misc.hip)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define NV_WAVE 64

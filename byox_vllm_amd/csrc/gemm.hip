@@ -40,6 +40,7 @@ struct GemmArgs {
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
   int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
+  int result_nt;   // 1: non-temporal result stores (quantised weights, epi 1 / 2 / 3): the result-store policy
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);
@@ -174,6 +175,7 @@ extern "C" int nv_gemm(const void* x, int64_t x_row_stride, const void* w, const
   NV_CHECK_ARG(mtiles <= 65535 && split_k <= 65535, "nv_gemm: M=%lld too large for one launch", (long long)M);
   a.epi = use_slabs ? 2 : (silu ? 1 : 0);
   a.rope = RopeArgs{};
+  a.result_nt = nv_result_policy();
   a.stats = SampleParts{};
   a.stream = (hipStream_t)stream;
   // Where the planner wants 128 rows x 192 columns per workgroup of int4 weights, the 32x32x16 kernel covers the same
@@ -253,6 +255,7 @@ extern "C" int nv_lm_head_sample(const void* x, int64_t x_row_stride, const void
   a.bm = plan_rows(M, K, a.ntw, 1);
   a.epi = 4;
   a.rope = RopeArgs{};
+  a.result_nt = nv_result_policy();
   a.wide = 0;
   a.mixed = 0;
   a.stats.P = (V + SAMPLE_PART_COLS - 1) / SAMPLE_PART_COLS;
@@ -350,7 +353,7 @@ extern "C" int nv_gemm_rope_kv_store(const void* x, int64_t x_row_stride, const 
   a.rope.positions = positions; a.rope.cos_sin = cos_sin; a.rope.slots = slot_mapping;
   a.rope.k_cache = (uint16_t*)k_cache; a.rope.v_cache = (uint16_t*)v_cache;
   a.rope.qn_w = (const uint16_t*)q_norm_w; a.rope.kn_w = (const uint16_t*)k_norm_w;
-  a.rope.eps = eps; a.rope.H = H; a.rope.Hkv = Hkv; a.rope.D = D;
+  a.rope.eps = eps; a.rope.H = H; a.rope.Hkv = Hkv; a.rope.D = D; a.result_nt = nv_result_policy();
   a.stream = (hipStream_t)stream;
   if (dtype == NV_BF16) nv_gemm_launch_bf16(a); else nv_gemm_launch_f16(a);
   NV_CHECK_LAUNCH();

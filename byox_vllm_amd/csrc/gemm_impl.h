@@ -75,7 +75,8 @@ constexpr int gemm_lds_bytes() {
 // launch); either one alone gains nothing.  The logits are stored with the default policy: non-temporal 8-byte
 // stores of four lanes per row took the launch from 92 to 110 us (no write combining), 6 us per step more than the
 // 39 MB of cache the logits buffer occupies cost.
-template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false>
+template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false, bool RNT = false>
+                                                            // RNT: results stored non-temporal (common.h out_store; EPI 1-3)
                                                             // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
                                                             //      4 = store + the sampler's per-part statistics (LM head)
@@ -420,7 +421,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 4 * sub);
       const f32x4 x2 = *reinterpret_cast<const f32x4*>(src + DD / 2 + 4 * sub);
       const int64_t t = live ? m0 + r : 0;
-      rope_finish<T>(x1, x2, ra, (int)blockIdx.x, t, sub, out + t * out_stride + (int64_t)blockIdx.x * DD, true, live);
+      rope_finish<T, RNT>(x1, x2, ra, (int)blockIdx.x, t, sub, out + t * out_stride + (int64_t)blockIdx.x * DD, true, live);
     }
     return;
   }
@@ -537,7 +538,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
                 gt * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * gt))));
             r[e] = sl * up;
           }
-          *reinterpret_cast<uint32_t*>(out + m * out_stride + j0) = pack2<T>(r[0], r[1]);
+          out_store<RNT>(reinterpret_cast<uint32_t*>(out + m * out_stride + j0), pack2<T>(r[0], r[1]));
         }
       }
     } else {
@@ -545,7 +546,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t m = m0 + 16 * i + c;
-        if (m < M && owns(j * TM + i)) *reinterpret_cast<f32x4*>(slab + m * N + nb) = acc[j][i];
+        if (m < M && owns(j * TM + i)) out_store<RNT>(reinterpret_cast<f32x4*>(slab + m * N + nb), acc[j][i]);
       }
     }
   }
@@ -563,7 +564,7 @@ __device__ __forceinline__ void gemm_body(const uint16_t* __restrict__ x, int64_
 // A workgroup has 8 wavefronts = 2 groups of 4: both groups own the same 4*NTW tiles, group 0 multiplies the first
 // two 32-deep k-steps of every K-block and group 1 the last two, so each SIMD holds two wavefronts whose
 // dequantisation (VALU) and MFMA streams overlap; the two partial accumulators are added through LDS at the end.
-template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false>
+template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false, bool RNT = false>
 __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                    const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[gemm_lds_bytes<BM, NTW, EPI>()];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = wave & 3, kg = wave >> 2;         // column group of 4 wavefronts, k-step group
-  gemm_body<T, WFMT, BM, NTW, EPI, STREAM>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, ra,
+  gemm_body<T, WFMT, BM, NTW, EPI, STREAM, RNT>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, ra,
                                            sp, lds_raw, wid, kg, (blockIdx.x * 4 + wid) * NTW);
 }
 
@@ -634,13 +635,14 @@ struct GemmArgs {
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
   int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
+  int result_nt;   // 1: non-temporal result stores (quantised weights, epi 1 / 2 / 3): the result-store policy
 };
 #endif
 
-template <typename T, int WFMT, int NTW, int EPI, bool STREAM = false>
+template <typename T, int WFMT, int NTW, int EPI, bool STREAM = false, bool RNT = false>
 static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 #define GO(BMV)                                                                                               \
-  gemm_kernel<T, WFMT, BMV, NTW, EPI, STREAM><<<grid, dim3(512), 0, a.stream>>>(                              \
+  gemm_kernel<T, WFMT, BMV, NTW, EPI, STREAM, RNT><<<grid, dim3(512), 0, a.stream>>>(                         \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,  \
       a.os, a.partial, a.M, a.N, a.K, a.split_k, a.rope, a.stats)
   switch (a.bm) {
@@ -654,6 +656,16 @@ static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 
 template <typename T, int WFMT, int NTW>
 static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
+  // the non-temporal result stores exist for the quantised formats only: a decoder whose weights fit the memory-side
+  // cache is a quantised one (dense models of that size are toys), and every instantiation costs build time
+  if constexpr (WFMT == NV_W_INT4 || WFMT == NV_W_INT8) {
+    if (a.result_nt && a.epi >= 1 && a.epi <= 3) {
+      if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1, false, true>(a, grid);
+      else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2, false, true>(a, grid);
+      else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3, false, true>(a, grid);
+      return;
+    }
+  }
   if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
   else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
   else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2>(a, grid);

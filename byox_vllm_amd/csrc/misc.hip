@@ -17,6 +17,17 @@ void nv_set_error(const char* fmt, ...) {
 extern "C" const char* nv_last_error(void) { return g_err; }
 extern "C" int nv_version(void) { return 100; }
 
+// Result-store policy (common.h out_store): read by the launch wrappers, so a captured launch keeps the policy that was
+// in force at capture time.  One word, written by set-up code only.
+static int g_result_policy = 0;
+int nv_result_policy() { return g_result_policy; }
+extern "C" int nv_set_result_policy(int nontemporal) {
+  NV_CHECK_ARG(nontemporal == 0 || nontemporal == 1, "nv_set_result_policy: %d is neither 0 nor 1", nontemporal);
+  g_result_policy = nontemporal;
+  return NV_OK;
+}
+extern "C" int nv_get_result_policy(void) { return g_result_policy; }
+
 // ---------------------------------------------------------------- silu * up
 template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* x, const u
 
 // One workgroup per row, the row held in registers between the reduction and the scaling: used for the
 // model's hidden-size rows (few rows, each a few KB, possibly still spread over split-K slabs).
-template <typename T, bool ADD, bool PARTIAL, int NT, int NV>
+template <typename T, bool ADD, bool PARTIAL, int NT, int NV, bool RNT>
 __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, const uint16_t* res,
                                                          const uint16_t* __restrict__ w, uint16_t* out,
                                                          uint16_t* res_out, int64_t rows, int hidden, int64_t x_stride,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, cons
         ss = fmaf(lo, lo, ss);
         ss = fmaf(hi, hi, ss);
       }
-      if (ADD) reinterpret_cast<u32x4*>(res_out + row * x_stride)[i] = r;
+      if (ADD) out_store<RNT>(&reinterpret_cast<u32x4*>(res_out + row * x_stride)[i], r);
     }
   }
   ss = wave_sum(ss);
@@ -141,18 +141,18 @@ __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, cons
         const float nhi = bits_to_f32<T>(f32_to_bits<T>(v[k][2 * j + 1] * inv));
         o[j] = pack2<T>(nlo * lo_f32<T>(ww[j]), nhi * hi_f32<T>(ww[j]));
       }
-      reinterpret_cast<u32x4*>(out + row * out_stride)[i] = o;
+      out_store<RNT>(&reinterpret_cast<u32x4*>(out + row * out_stride)[i], o);
     }
   }
 }
 
-template <typename T, bool ADD, bool PARTIAL>
+template <typename T, bool ADD, bool PARTIAL, bool RNT>
 static bool launch_norm_row(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
                             int hidden, int64_t xs, int64_t os, float eps, hipStream_t s, const float* part,
                             int nparts) {
   const int nvec = hidden >> 3;
 #define ROW_GO(NTV, NVV)                                                                                             \
-  rmsnorm_row_kernel<T, ADD, PARTIAL, NTV, NVV><<<dim3((unsigned)rows), dim3(NTV), 0, s>>>(                          \
+  rmsnorm_row_kernel<T, ADD, PARTIAL, NTV, NVV, RNT><<<dim3((unsigned)rows), dim3(NTV), 0, s>>>(                     \
       (const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out, rows, hidden, \
       xs, os, eps, part, nparts)
   if (nvec <= 128) ROW_GO(128, 1);
@@ -171,9 +171,12 @@ static int launch_norm(const void* x, const void* res, const void* w, void* out,
   if (rows == 0) return NV_OK;
   // few long rows: one workgroup per row; many short rows (per-head norms): one wavefront per row
   if ((PARTIAL || hidden >= 512) && rows <= 0x7fffffff) {
-    const bool ok = (dtype == NV_BF16)
-        ? launch_norm_row<bf16_t, ADD, PARTIAL>(x, res, w, out, res_out, rows, hidden, xs, os, eps, s, part, nparts)
-        : launch_norm_row<f16_t, ADD, PARTIAL>(x, res, w, out, res_out, rows, hidden, xs, os, eps, s, part, nparts);
+    // the model's hidden-size rows are what the next GEMM reads: they follow the result-store policy
+    const bool nt = nv_result_policy() != 0;
+#define ROW(TT, RNT) launch_norm_row<TT, ADD, PARTIAL, RNT>(x, res, w, out, res_out, rows, hidden, xs, os, eps, s, part, nparts)
+    const bool ok = (dtype == NV_BF16) ? (nt ? ROW(bf16_t, true) : ROW(bf16_t, false))
+                                       : (nt ? ROW(f16_t, true) : ROW(f16_t, false));
+#undef ROW
     if (ok) {
       NV_CHECK_LAUNCH();
       return NV_OK;

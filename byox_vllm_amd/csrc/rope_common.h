@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x4 round4(f32x4 v) {
 // first half (x1) and the matching four of the second half (x2), already rounded to the model dtype.
 // `row` = the head's place in the qkv buffer; write_v_row: value heads are written there too (they are not there yet).
 // Every lane of a head group must make the call (shuffles); lanes with live == false only take part in those.
-template <typename T>
+template <typename T, bool NT = false>   // NT: q/k/v rows and cache rows stored non-temporal (common.h out_store)
 __device__ __forceinline__ void rope_finish(f32x4 x1, f32x4 x2, const RopeArgs& ra, int hs, int64_t t, int sub,
                                             uint16_t* row, bool write_v_row, bool live) {
   const int D = ra.D, H = ra.H, Hkv = ra.Hkv, lph = D >> 3;
@@ -46,13 +46,13 @@ __device__ __forceinline__ void rope_finish(f32x4 x1, f32x4 x2, const RopeArgs& 
     if (!live) return;
     const u32x2 w1 = pack4<T>(x1), w2 = pack4<T>(x2);
     if (write_v_row) {
-      *reinterpret_cast<u32x2*>(row + c1) = w1;
-      *reinterpret_cast<u32x2*>(row + c2) = w2;
+      out_store<NT>(reinterpret_cast<u32x2*>(row + c1), w1);
+      out_store<NT>(reinterpret_cast<u32x2*>(row + c2), w2);
     }
     if (ra.v_cache && slot >= 0) {
       uint16_t* dst = ra.v_cache + ((int64_t)slot * Hkv + (hs - H - Hkv)) * D;
-      *reinterpret_cast<u32x2*>(dst + c1) = w1;
-      *reinterpret_cast<u32x2*>(dst + c2) = w2;
+      out_store<NT>(reinterpret_cast<u32x2*>(dst + c1), w1);
+      out_store<NT>(reinterpret_cast<u32x2*>(dst + c2), w2);
     }
     return;
   }
@@ -80,11 +80,11 @@ __device__ __forceinline__ void rope_finish(f32x4 x1, f32x4 x2, const RopeArgs& 
     y2[j] = __fadd_rn(__fmul_rn(x2[j], c[j]), __fmul_rn(x1[j], sn[j]));
   }
   const u32x2 w1 = pack4<T>(y1), w2 = pack4<T>(y2);
-  *reinterpret_cast<u32x2*>(row + c1) = w1;
-  *reinterpret_cast<u32x2*>(row + c2) = w2;
+  out_store<NT>(reinterpret_cast<u32x2*>(row + c1), w1);
+  out_store<NT>(reinterpret_cast<u32x2*>(row + c2), w2);
   if (is_k && ra.k_cache && slot >= 0) {
     uint16_t* dst = ra.k_cache + ((int64_t)slot * Hkv + (hs - H)) * D;
-    *reinterpret_cast<u32x2*>(dst + c1) = w1;
-    *reinterpret_cast<u32x2*>(dst + c2) = w2;
+    out_store<NT>(reinterpret_cast<u32x2*>(dst + c1), w1);
+    out_store<NT>(reinterpret_cast<u32x2*>(dst + c2), w2);
   }
 }

@@ -11,7 +11,7 @@
 #include "rope_common.h"
 #include "splitk.h"
 
-template <typename T, bool PARTIAL>  // PARTIAL: the qkv rows exist only as split-K slabs
+template <typename T, bool PARTIAL, bool NT>  // PARTIAL: the qkv rows exist only as split-K slabs; NT: common.h out_store
 __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride, RopeArgs ra, int64_t ntok,
                                                       const float* __restrict__ part, int nparts,
                                                       const uint16_t* __restrict__ bias) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row
     x1 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c1));
     x2 = unpack4<T>(*reinterpret_cast<const u32x2*>(row + c2));
   }
-  rope_finish<T>(x1, x2, ra, hs, t, sub, row, PARTIAL, live);
+  rope_finish<T, NT>(x1, x2, ra, hs, t, sub, row, PARTIAL, live);
 }
 
 template <typename T>
@@ -96,10 +96,12 @@ static int rope_launch(void* qkv, int64_t qkv_row_stride, const int64_t* positio
   ra.positions = positions; ra.cos_sin = cos_sin; ra.slots = slot_mapping; ra.k_cache = (uint16_t*)k_cache;
   ra.v_cache = (uint16_t*)v_cache; ra.qn_w = (const uint16_t*)q_norm_w; ra.kn_w = (const uint16_t*)k_norm_w;
   ra.eps = eps; ra.H = H; ra.Hkv = Hkv; ra.D = D;
-#define ROPE_GO(TT, PP) \
-  rope_kv_kernel<TT, PP><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, ra, T, partials, num_partials, (const uint16_t*)bias)
-  if (dtype == NV_BF16) { if (partials) ROPE_GO(bf16_t, true); else ROPE_GO(bf16_t, false); }
-  else                  { if (partials) ROPE_GO(f16_t, true); else ROPE_GO(f16_t, false); }
+#define ROPE_GO(TT, PP, NT) \
+  rope_kv_kernel<TT, PP, NT><<<grid, block, 0, s>>>((uint16_t*)qkv, qkv_row_stride, ra, T, partials, num_partials, (const uint16_t*)bias)
+#define ROPE_PICK(TT, PP) do { if (nv_result_policy()) ROPE_GO(TT, PP, true); else ROPE_GO(TT, PP, false); } while (0)
+  if (dtype == NV_BF16) { if (partials) ROPE_PICK(bf16_t, true); else ROPE_PICK(bf16_t, false); }
+  else                  { if (partials) ROPE_PICK(f16_t, true); else ROPE_PICK(f16_t, false); }
+#undef ROPE_PICK
 #undef ROPE_GO
   NV_CHECK_LAUNCH();
   return NV_OK;

@@ -47,6 +47,22 @@ class PendingReduce:
         self.value = value
 
 
+class result_policy:
+    """``with result_policy(1):`` — launches made inside store the results the next launch reads non-temporal
+    (include/nv_hip.h nv_set_result_policy; a captured launch keeps the policy it was captured under).  The setting is
+    one word per process, so it is restored on the way out: runners with different policies can share a process."""
+
+    def __init__(self, nontemporal: int):
+        self.mask = int(nontemporal)
+
+    def __enter__(self):
+        self.previous = lib().nv_get_result_policy()
+        check(lib().nv_set_result_policy(self.mask), "nv_set_result_policy")
+
+    def __exit__(self, *exc):
+        check(lib().nv_set_result_policy(self.previous), "nv_set_result_policy")
+
+
 def _require_device_weight(w, what: str) -> None:
     """A LinearWeight built from host tensors would hand the kernel a host pointer (a GPU memory fault, not an error
     code): refuse it here."""

@@ -1039,3 +1039,53 @@ def test_bad_arguments_are_rejected_not_launched():
         kernels.rms_norm(dev(torch.zeros(4, 128)), dev(torch.ones(128)), 1e-6)      # fp32 is not a HIP-path dtype
     with pytest.raises(RuntimeError, match="no CPU compute path"):
         kernels.rms_norm(torch.zeros(4, 128, dtype=torch.bfloat16), torch.ones(128, dtype=torch.bfloat16), 1e-6)
+
+
+@pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
+def test_result_store_policy_changes_no_bit(fmt):
+    """nv_set_result_policy only picks the cache policy of the stores: normalised rows, residual rows, SiLU(gate)*up
+    rows, split-K slabs (through the norm that sums them) and the q/k/v + cache rows of both RoPE forms are the same
+    bits with it on; the setting is restored by the context manager; values other than 0 and 1 are refused."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd._C import lib
+    from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
+    g = torch.Generator().manual_seed(len(fmt))
+    dt = torch.bfloat16
+    M, K, I, H, Hkv, d, bs, nb, mask = 100, 1024, 384, 4, 2, 64, 16, 12, 1
+    x = dev(torch.randn(M, K, generator=g).to(dt))
+    res = dev(torch.randn(M, K, generator=g).to(dt))
+    nw = dev((1 + 0.1 * torch.randn(K, generator=g)).to(dt))
+    w_gu = LinearWeight.make(dev(interleave_gate_up((torch.randn(2 * I, K, generator=g) * 0.05).to(dt))), fmt)
+    w_o = LinearWeight.make(dev((torch.randn(K, K, generator=g) * 0.05).to(dt)), fmt)
+    w_qkv = LinearWeight.make(dev((torch.randn((H + 2 * Hkv) * d, K, generator=g) * 0.05).to(dt)), fmt)
+    pos = dev(torch.randint(0, 200, (M,), generator=g))
+    slots = dev(torch.randperm(nb * bs, generator=g)[:M].to(torch.int32))
+    table = dev(L.build_cos_sin_cache(d, 256, 1e6))
+
+    def everything():
+        out = {}
+        out["norm"] = kernels.rms_norm(x, nw, 1e-6)
+        out["add_norm"], out["residual"] = kernels.add_rms_norm(x, res.clone(), nw, 1e-6)
+        out["act"] = kernels.gemm(x, w_gu, silu_mul=True)
+        slabs = kernels.gemm(x, w_o, split_k=2, partial_out=True)
+        out["slab_norm"], out["slab_residual"] = kernels.add_rms_norm(slabs, res.clone(), nw, 1e-6)
+        kc, vc = (dev(torch.zeros(nb, bs, Hkv, d, dtype=dt)) for _ in range(2))
+        out["qkv_fused"] = kernels.gemm_rope_kv_store(x, w_qkv, None, pos, table, H, Hkv, d, slot_mapping=slots,
+                                                      k_cache=kc, v_cache=vc)
+        out["k_fused"], out["v_fused"] = kc, vc
+        kc2, vc2 = (dev(torch.zeros(nb, bs, Hkv, d, dtype=dt)) for _ in range(2))
+        qkv = kernels.gemm(x, w_qkv, split_k=1)
+        kernels.rope_kv_store(qkv, pos, table, H, Hkv, d, slot_mapping=slots, k_cache=kc2, v_cache=vc2)
+        out["qkv_two"], out["k_two"], out["v_two"] = qkv, kc2, vc2
+        torch.cuda.synchronize()
+        return {k: v.cpu() for k, v in out.items()}
+
+    assert lib().nv_get_result_policy() == 0
+    plain = everything()
+    with kernels.result_policy(mask):
+        assert lib().nv_get_result_policy() == mask
+        hinted = everything()
+    assert lib().nv_get_result_policy() == 0
+    for k in plain:
+        assert torch.equal(plain[k], hinted[k]), k
+    assert lib().nv_set_result_policy(2) != 0 and lib().nv_get_result_policy() == 0

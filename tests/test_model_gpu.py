@@ -394,6 +394,41 @@ def test_graph_replay_equals_eager(golden):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("eager", [True, False])
+def test_result_store_policy_changes_no_token_and_no_logit(golden, monkeypatch, eager):
+    """The tiny model's weights fit the memory-side cache, so its decode steps run under the non-temporal result-store
+    policy; forced off (NV_RESULT_POLICY=0) the same steps give the same tokens and bit-identical KV-cache rows."""
+    from byox_vllm_amd._C import lib
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    outs = []
+    for forced in (None, "0"):
+        if forced is None:
+            monkeypatch.delenv("NV_RESULT_POLICY", raising=False)
+        else:
+            monkeypatch.setenv("NV_RESULT_POLICY", forced)
+        runner = make_runner(cfg, weights, enforce_eager=eager, max_num_seqs=8)
+        assert runner.decode_result_policy == (1 if forced is None else 0)
+        rng = np.random.RandomState(11)
+        seqs = []
+        for i, n in enumerate((7, 18, 31)):
+            s = Sequence(rng.randint(0, 256, size=n).tolist(), BS, SamplingParams(temperature=0.0, max_tokens=4))
+            s.block_table = list(range(3 * i, 3 * i + 3))
+            seqs.append(s)
+        toks = [runner.run(seqs, True)]
+        for _ in range(3):
+            for s, tkn in zip(seqs, toks[-1]):
+                s.append_token(tkn)
+            toks.append(runner.run(seqs, False))
+        assert lib().nv_get_result_policy() == 0          # the setting does not leak out of a step
+        outs.append((toks, runner.kv_cache[:, :, :9].cpu().clone()))
+        runner.exit()
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_device_side_bookkeeping_equals_host_packing(golden, monkeypatch):
     """Decode steps continued on the device (ids from the previous step's tokens, positions + 1, slots from the device's
     block tables) against the same steps packed on the host every time: identical tokens over block boundaries, a
