@@ -146,6 +146,79 @@ __global__ __launch_bounds__(NT) void rmsnorm_row_kernel(const uint16_t* x, cons
   }
 }
 
+// The same with EPT = 4 (or 2) elements per thread (8- or 4-byte loads of the 16-bit rows, one float4 / float2 per slab):
+// more wavefronts per row, for rows short enough that one workgroup covers them.  A norm launch is a chain of memory
+// latencies, and more wavefronts per row keep more of the row's loads in flight at once.
+template <typename T, bool ADD, bool PARTIAL, bool RNT, int EPT, int NT>
+__global__ __launch_bounds__(NT) void rmsnorm_rowe_kernel(const uint16_t* x, const uint16_t* res,
+                                                          const uint16_t* __restrict__ w, uint16_t* out,
+                                                          uint16_t* res_out, int64_t rows, int hidden, int64_t x_stride,
+                                                          int64_t out_stride, float eps, const float* __restrict__ part,
+                                                          int nparts) {
+  typedef uint32_t pk_t __attribute__((ext_vector_type(EPT / 2)));   // EPT 16-bit values
+  typedef float fv_t __attribute__((ext_vector_type(EPT)));
+  __shared__ float s_part[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const bool live = tid < hidden / EPT;
+  const int i = live ? tid : 0;
+  const pk_t wreg = reinterpret_cast<const pk_t*>(w)[i];
+  float a[EPT];
+  if (PARTIAL) {
+    const float* p = part + row * hidden + EPT * i;
+    const int64_t slab = rows * hidden;
+    fv_t acc = *reinterpret_cast<const fv_t*>(p);
+    int z = 1;
+    for (; z + 8 <= nparts; z += 8) {      // eight slabs' loads go out before the first add; slab order is kept
+      fv_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const fv_t*>(p + (z + k) * slab);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    {
+      fv_t v[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) v[k] = *reinterpret_cast<const fv_t*>(p + (z + k < nparts ? z + k : 0) * slab);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) if (z + k < nparts) acc += v[k];
+    }
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) a[j] = bits_to_f32<T>(f32_to_bits<T>(acc[j]));   // what the GEMM's reduction would store
+  } else {
+    const pk_t xv = reinterpret_cast<const pk_t*>(x + row * x_stride)[i];
+#pragma unroll
+    for (int j = 0; j < EPT / 2; ++j) { a[2 * j] = lo_f32<T>(xv[j]); a[2 * j + 1] = hi_f32<T>(xv[j]); }
+  }
+  if (ADD) {
+    const pk_t rv = reinterpret_cast<const pk_t*>(res + row * x_stride)[i];
+    pk_t r;
+#pragma unroll
+    for (int j = 0; j < EPT / 2; ++j) {
+      a[2 * j] += lo_f32<T>(rv[j]);
+      a[2 * j + 1] += hi_f32<T>(rv[j]);
+      r[j] = pack2<T>(a[2 * j], a[2 * j + 1]);
+    }
+    if (live) out_store<RNT>(&reinterpret_cast<pk_t*>(res_out + row * x_stride)[i], r);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) ss = fmaf(a[j], a[j], ss);
+  ss = wave_sum(live ? ss : 0.f);
+  if (lane == 0) s_part[wid] = ss;
+  __syncthreads();
+  ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) ss += s_part[k];
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  pk_t o;
+#pragma unroll
+  for (int j = 0; j < EPT / 2; ++j)
+    o[j] = pack2<T>(bits_to_f32<T>(f32_to_bits<T>(a[2 * j] * inv)) * lo_f32<T>(wreg[j]),
+                    bits_to_f32<T>(f32_to_bits<T>(a[2 * j + 1] * inv)) * hi_f32<T>(wreg[j]));
+  if (live) out_store<RNT>(&reinterpret_cast<pk_t*>(out + row * out_stride)[i], o);
+}
+
 template <typename T, bool ADD, bool PARTIAL, bool RNT>
 static bool launch_norm_row(const void* x, const void* res, const void* w, void* out, void* res_out, int64_t rows,
                             int hidden, int64_t xs, int64_t os, float eps, hipStream_t s, const float* part,
@@ -155,12 +228,22 @@ static bool launch_norm_row(const void* x, const void* res, const void* w, void*
   rmsnorm_row_kernel<T, ADD, PARTIAL, NTV, NVV, RNT><<<dim3((unsigned)rows), dim3(NTV), 0, s>>>(                     \
       (const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out, rows, hidden, \
       xs, os, eps, part, nparts)
-  if (nvec <= 128) ROW_GO(128, 1);
-  else if (nvec <= 256) ROW_GO(256, 1);
-  else if (nvec <= 512) ROW_GO(256, 2);
+#define ROWE_GO(EPTV, NTV)                                                                                           \
+  rmsnorm_rowe_kernel<T, ADD, PARTIAL, RNT, EPTV, NTV><<<dim3((unsigned)rows), dim3(NTV), 0, s>>>(                    \
+      (const uint16_t*)x, (const uint16_t*)res, (const uint16_t*)w, (uint16_t*)out, (uint16_t*)res_out, rows, hidden, \
+      xs, os, eps, part, nparts)
+  // hidden <= 4096: four elements per thread, one workgroup of up to 1024 threads per row.  Measured on the 896-wide rows of Qwen2-0.5B (48
+  // launches per decode step): 8 elements per thread in 2 wavefronts 4.6 us per launch, 4 per thread in 4 wavefronts
+  // 0.15-0.25 us less, 2 per thread in 8 wavefronts no better, all 16 per lane in one wavefront 0.65 us more.
+  // The 3584-wide rows of Qwen2-7B (56 launches per step): 6.1 us with 8 elements per thread twice in 256 threads,
+  // 0.56 us less with 4 per thread in a workgroup of 1024.
+  if (nvec <= 128) ROWE_GO(4, 256);
+  else if (nvec <= 256) ROWE_GO(4, 512);
+  else if (nvec <= 512) ROWE_GO(4, 1024);
   else if (nvec <= 1024) ROW_GO(256, 4);
   else return false;
 #undef ROW_GO
+#undef ROWE_GO
   return true;
 }
 
