@@ -302,12 +302,32 @@ __global__ __launch_bounds__(256) void sample_parts_pick_kernel(const uint16_t* 
   float* lm = pick_lds;
   float* lw = pick_lds + P;
   Best top = {-INFINITY, 0x7fffffff};            // (maximum, part): parts are in column order, so the lowest part wins ties
-#pragma unroll 4
-  for (int k = tid; k < P; k += 256) {
-    const float m = pm[k];
-    lm[k] = m;
-    lw[k] = ps[k];
-    top = better(top, Best{m, k});
+  // The first 12 x 256 parts (a 151936-entry vocabulary has 2374) are fetched with all loads in flight at once, on
+  // clamped indices so that no branch splits them: the kernel is one workgroup per row and this read is a third of it.
+  {
+    constexpr int DEPTH = 12;
+    float m[DEPTH], w[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const int k = tid + 256 * j, kk = k < P ? k : P - 1;
+      m[j] = pm[kk];
+      w[j] = ps[kk];
+    }
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const int k = tid + 256 * j;
+      if (k < P) {
+        lm[k] = m[j];
+        lw[k] = w[j];
+        top = better(top, Best{m[j], k});
+      }
+    }
+    for (int k = tid + 256 * DEPTH; k < P; k += 256) {
+      const float mk = pm[k];
+      lm[k] = mk;
+      lw[k] = ps[k];
+      top = better(top, Best{mk, k});
+    }
   }
   top = wave_best(top);
   if (lane == 0) {
