@@ -1044,12 +1044,18 @@ static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
   }
   if (groups > 512 && max_tokens <= 512) return 1;
   if (D == 64) return groups > 256 ? 2 : 8;       // with non-temporal loads 8 beat 4 at 256 groups (14.08 / 14.36 us)
-  return groups > 256 ? 2 : (groups > 128 ? 4 : 8);
+  // 128-wide heads keep 32 KB in flight per wavefront (two 16 KB chunks), so 512 wavefronts already cover the memory
+  // system's latency: with the register-set ring one wavefront per group wins from 512 groups on (47.1 / 48.8 / 50.6 /
+  // 52.2 us with 1 / 2 / 4 / 8 at 128 x 4 heads, context 1024; 182 / 191 at 4096; 95.0 / 96.1 at 1024 groups), two at
+  // 256 groups (24.8 against 26.7 with 4, 36.6 with 1).  One per group only while the table holds at most 2048 tokens:
+  // beyond that a lone long sequence of a ragged batch would stream for longer than the rest of the launch takes.
+  if (groups >= 512 && max_tokens <= 2048) return 1;
+  return groups >= 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
 // Revision of paged_decode_kernel's memory access pattern.  Bumped with every change that can alter the bytes a launch
 // moves; counter collections name the revision they were taken on, so a stale one is recognised.
-#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03b"
+#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03c"
 extern "C" const char* nv_paged_attn_decode_kernel_tag(void) { return NV_PAGED_DECODE_KERNEL_TAG; }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
