@@ -130,7 +130,7 @@ class ModelRunner:
 
     def _pick_decode_result_policy(self) -> int:
         """Non-temporal result stores for DECODE steps of a model whose decoder weights fit the memory-side cache
-        (Qwen2-0.5B in int4: 179 MB, measured 1.1 % per step); 0 otherwise (larger models lose 1-2 % with them, and a
+        (Qwen2-0.5B in int4: 179 MB, measured 1.6 % per step); 0 otherwise (larger models lose 1-2 % with them, and a
         prefill's results are too large to gain).  NV_RESULT_POLICY=0/1 overrides the choice."""
         from byox_vllm_amd.layers.linear import LinearBase
         forced = os.environ.get("NV_RESULT_POLICY")
