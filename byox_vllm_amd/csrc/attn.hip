@@ -298,7 +298,12 @@ __device__ __forceinline__ bool ring_round(F& body, std::integer_sequence<int, J
 // ------------------------------------------------------------------ decode
 // NW wavefronts per workgroup share one (sequence, kv head, split); wavefront w takes chunks
 // split*NW + w, + NW*splits, ...  Loads run one chunk ahead of the MFMAs and block-table lookups two ahead.
-template <typename T, int D, int NW, bool NT>
+// ADAPT (used where a launch has so many groups that one wavefront each would do, see decode_waves): the workgroup is
+// launched with NW wavefronts, and every group decides from the launch's context lengths how many of them it keeps -
+// one if it is about as long as the average group, two from 1.5 times the average, four (if launched with four) from
+// 3 times - and the others leave at once.  A batch of equal lengths then runs as if launched with one wavefront per
+// group (the fastest form there), while a long sequence of a ragged batch is not left to a single wavefront.
+template <typename T, int D, int NW, bool NT, bool ADAPT = false>
 __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const uint16_t* __restrict__ k_cache,
     const uint16_t* __restrict__ v_cache, const int32_t* __restrict__ block_tables, int bt_stride,
@@ -321,6 +326,28 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
   const uint16_t* v_base = v_cache + (int64_t)kvh * D;
   const int32_t* bt_row = block_tables + (int64_t)b * bt_stride;
 
+  int nwv = NW;   // wavefronts of this workgroup that take part
+  int len_sum = 0;
+  if constexpr (ADAPT) {
+    for (int i = lane; i < (int)gridDim.z; i += 64) len_sum += context_lens[i];
+  }
+  // The launch's average length decides; wavefront 0 stays in any case and its first chunk is chunk 0 either way (the
+  // adaptive form is launched without KV splits), so it asks only after its first loads are out.
+  auto decide = [&]() {
+    int total = len_sum;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) total += __shfl_xor(total, o, 64);
+    const int64_t sum = __builtin_amdgcn_readfirstlane(total), mine = (int64_t)n_keys * (int)gridDim.z;
+    nwv = mine >= 3 * sum ? 4 : (2 * mine >= 3 * sum ? 2 : 1);
+    nwv = nwv > NW ? NW : nwv;
+  };
+  if constexpr (ADAPT) {
+    if (wid != 0) {
+      decide();
+      if (wid >= nwv) return;     // before any barrier: the hardware barrier counts the wavefronts still alive
+    }
+  }
+
   // Q^T as the B operand: lane (c, g) holds q[head c][32 ks + 8 g ..+7]
   frag_t qf[KS];
   {
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
   for (int m = 0; m < NM; ++m) st.acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int n_chunks = (n_keys + 31) >> 5;
-  const int step = splits * NW;
+  int step = splits * nwv;
   const int max_blk = bt_stride - 1;
   // Rows of a chunk's two tiles; a tile that starts past the end re-reads the chunk's first tile (masked anyway).
   // Chunks are dealt round-robin, so at any moment the wavefronts of a workgroup stream one contiguous region of
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
   // issued before the MFMAs of the current one and nothing is ever copied from a set that is still in flight (a
   // copy would wait for its loads), so each wavefront keeps one chunk of HBM traffic in flight behind its compute.
   // Rows are looked up one chunk further ahead than the loads.
-  int ch = split * NW + wid;
+  int ch = ADAPT ? wid : split * nwv + wid;
   auto compute = [&](ChunkRegs<T, D>& r, int chunk) {
     const int base = chunk << 5;
     if (base + 32 <= n_keys) chunk_compute<T, D, false, false>(st, r, qf, base, n_keys, n_keys, scale2);
@@ -411,6 +438,10 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
     ChunkRegs<T, D> rs[DEPTH];
     int64_t rw[2];
     chunk_load<T, D, false, NT>(rs[0], k_base, v_base, row_stride, rows0, INT64_MAX);
+    if constexpr (ADAPT) {
+      if (wid == 0) decide();
+      step = splits * nwv;
+    }
 #pragma unroll
     for (int j = 1; j < DEPTH - 1; ++j) {
       int64_t rj[2];
@@ -444,6 +475,8 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
     };
     while (!ring_round(body, std::make_integer_sequence<int, DEPTH>{})) {
     }
+   } else if constexpr (ADAPT) {
+    if (wid == 0) decide();    // a group without keys (a padding row): the other wavefront has left, know it
    }
   }
 
@@ -454,6 +487,85 @@ __global__ __launch_bounds__(NW * 64, (NW < 4 ? 2 : 1)) void paged_decode_kernel
   float l = st.l;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
+  if constexpr (ADAPT) {
+    // the same merge over the nwv (1, 2 or 4) wavefronts that stayed; each finishes 4 / nwv of the register indices
+    static_assert(NW == 2 || NW == 4, "the adaptive form is launched with two or four wavefronts");
+    float M = st.m, L = l, f[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) f[w] = w == 0 ? 1.f : 0.f;
+    if (nwv > 1) {
+      if (g == 0) {
+        s_m[wid][c] = st.m;
+        s_l[wid][c] = l;
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_acc[wid][m * 4 + r][lane] = st.acc[m][r];
+      __syncthreads();
+      M = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w < nwv) M = fmaxf(M, s_m[w][c]);
+      L = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        f[w] = 0.f;
+        if (w < nwv) {
+          const float mw = s_m[w][c];
+          f[w] = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
+          L += s_l[w][c] * f[w];
+        }
+      }
+    }
+    if (c >= G) return;
+    const int head = kvh * G + c;
+    const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+    const int64_t slot = ((int64_t)b * H + head) * splits + split;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      if (rr >= 4 / nwv) break;
+      const int r = wid + rr * nwv;
+      const int d0 = NM * (4 * g + r);
+      float o[NM];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        float v = 0.f;
+        if (nwv == 1) {
+          // r == rr here; a register array cannot be indexed by a run-time value without spilling, so pick by compare
+          v = rr == 0 ? st.acc[m][0] : rr == 1 ? st.acc[m][1] : rr == 2 ? st.acc[m][2] : st.acc[m][3];
+        } else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+            if (w < nwv) v += s_acc[w][m * 4 + r][lane] * f[w];
+        }
+        o[m] = v;
+      }
+      if (splits == 1) {
+        uint16_t* dst = out + (int64_t)b * out_stride + (int64_t)head * D + d0;
+        if constexpr (NM == 8) {
+          u32x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+          *reinterpret_cast<u32x4*>(dst) = w;
+        } else {
+          u32x2 w;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) w[e] = pack2<T>(o[2 * e] * inv, o[2 * e + 1] * inv);
+          *reinterpret_cast<u32x2*>(dst) = w;
+        }
+      } else {
+        float* dst = part_o + slot * D + d0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) dst[m] = o[m];
+      }
+    }
+    if (splits > 1 && g == 0 && wid == 0) {
+      part_ml[slot * 2] = M;
+      part_ml[slot * 2 + 1] = L;
+    }
+    return;
+  }
   float M, L, f[NW];
   if constexpr (NW == 1) {
     M = st.m;
@@ -1034,28 +1146,37 @@ __global__ __launch_bounds__(256, 2) void prefill_lds_kernel(
 // The choice depends on the launch shape only, never on the context lengths, so a captured launch stays valid for
 // every replay.  One wavefront per group only where the block table cannot describe more than 512 tokens per
 // sequence: a long straggler of a ragged batch would otherwise stream at a single wavefront's rate.
-// NV_ATTN_WAVES (1, 2, 4, 8, or 16 at D=64) selects another instantiation; read on every call so one process can
-// compare them.
-static int decode_waves(int D, int64_t groups, int64_t max_tokens) {
+// NV_ATTN_WAVES (1, 2, 4, 8, or 16 at D=64; 0 = the adaptive form at D=128) selects another instantiation; read on
+// every call so one process can compare them.
+static int decode_waves(int D, int64_t groups, int64_t max_tokens, int splits) {
   if (const char* e = getenv("NV_ATTN_WAVES")) {
     const int forced = atoi(e);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     if (forced == 16) return D == 128 ? 8 : 16;
+    if (forced == 0 && D == 128 && splits == 1 && e[0] == '0') return 0;
   }
   if (groups > 512 && max_tokens <= 512) return 1;
   if (D == 64) return groups > 256 ? 2 : 8;       // with non-temporal loads 8 beat 4 at 256 groups (14.08 / 14.36 us)
   // 128-wide heads keep 32 KB in flight per wavefront (two 16 KB chunks), so 512 wavefronts already cover the memory
-  // system's latency: with the register-set ring one wavefront per group wins from 512 groups on (47.1 / 48.8 / 50.6 /
-  // 52.2 us with 1 / 2 / 4 / 8 at 128 x 4 heads, context 1024; 182 / 191 at 4096; 95.0 / 96.1 at 1024 groups), two at
-  // 256 groups (24.8 against 26.7 with 4, 36.6 with 1).  One per group only while the table holds at most 2048 tokens:
-  // beyond that a lone long sequence of a ragged batch would stream for longer than the rest of the launch takes.
-  if (groups >= 512 && max_tokens <= 2048) return 1;
+  // system's latency: with the register-set ring one wavefront per group is the fastest form for a batch of EQUAL
+  // lengths from 512 groups on (46.2 / 49.1 / 50.6 / 52.2 us with 1 / 2 / 4 / 8 at 128 x 4 heads, context 1024; 182 /
+  // 191 at 4096; 190.6 / 197.3 at 2048 groups), two at 256 groups (24.8 against 26.7 with 4, 36.6 with 1) - and the
+  // worst for a ragged one (one sequence of 1280 tokens among 127 of 256: 45.9 / 30.9 / 24.5 us; 16 of 1280 among 112
+  // of 640: 52.3 / 43.5).  Up to 1024 groups the launch therefore takes the adaptive form (0: two wavefronts per
+  // workgroup, each group keeping one or both by its own length against the launch's average): 47.9 us on the equal
+  // batch, 28.9 and 40.4 us on the two ragged ones - ahead of both fixed choices there; four wavefronts per workgroup
+  // would need 321 registers each and leave room for one workgroup per CU.  Beyond 1024 groups a CU works through
+  // eight or more workgroups, a long one has company while it streams, and the wavefronts that would only leave
+  // again cost more than they save (205.8 against 190.6 us at 2048 groups): one per group where the table holds at
+  // most 2048 tokens, two otherwise.
+  if (splits == 1 && groups >= 512 && groups <= 1024) return 0;
+  if (groups > 1024 && max_tokens <= 2048) return 1;
   return groups >= 256 ? 2 : (groups > 128 ? 4 : 8);
 }
 
 // Revision of paged_decode_kernel's memory access pattern.  Bumped with every change that can alter the bytes a launch
 // moves; counter collections name the revision they were taken on, so a stale one is recognised.
-#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03c"
+#define NV_PAGED_DECODE_KERNEL_TAG "decode-r03d"
 extern "C" const char* nv_paged_attn_decode_kernel_tag(void) { return NV_PAGED_DECODE_KERNEL_TAG; }
 
 extern "C" int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context) {
@@ -1101,7 +1222,7 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
   const float scale2 = scale * LOG2E;
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
-  const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits, (int64_t)bt_stride * block_size);
+  const int nw = decode_waves(D, (int64_t)B * Hkv * num_splits, (int64_t)bt_stride * block_size, num_splits);
   dim3 grid(num_splits, Hkv, B);
   // non-temporal K/V loads: 64-wide heads, and a cache region behind this launch's block tables of at least 8 MB
   bool nt = D == 64 && (int64_t)B * Hkv * bt_stride * block_size * D * 4 >= ((int64_t)8 << 20);
@@ -1117,7 +1238,8 @@ static int paged_decode_go(const void* q, int64_t q_row_stride, const void* k_ca
 #define LAUNCH_DEC_T(TT)                                                         \
   do {                                                                           \
     if (D == 128) {                                                              \
-      if (nw == 1) LAUNCH_DEC(TT, 128, 1);                                       \
+      if (nw == 0) paged_decode_kernel<TT, 128, 2, false, true><<<grid, dim3(128), 0, s>>>(LAUNCH_DEC_ARGS); \
+      else if (nw == 1) LAUNCH_DEC(TT, 128, 1);                                  \
       else if (nw == 2) LAUNCH_DEC(TT, 128, 2);                                  \
       else if (nw == 4) LAUNCH_DEC(TT, 128, 4);                                  \
       else LAUNCH_DEC(TT, 128, 8);                                               \

@@ -254,6 +254,54 @@ def test_paged_decode_chunk_census(D, H, Hkv, n, splits, waves, monkeypatch):
     assert torch.allclose(got.float().cpu().sum(-1), torch.ones(2, H), atol=2e-2)   # masses sum to one
 
 
+ADAPTIVE_CASES = [
+    dict(B=4, H=28, Hkv=4, D=128, bs=256, lens=[1024, 1057, 2049, 31]),     # one group keeps both wavefronts, three keep one
+    dict(B=4, H=28, Hkv=4, D=128, bs=256, lens=[700, 700, 700, 700]),       # equal lengths: every group keeps one
+    dict(B=5, H=16, Hkv=8, D=128, bs=32, lens=[0, 33, 0, 900, 64]),         # padding rows pull the average down
+    dict(B=3, H=8, Hkv=2, D=128, bs=16, lens=[515, 258, 1]),                # zero-padded query slots
+]
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("cfg", ADAPTIVE_CASES)
+def test_paged_decode_adaptive_wavefronts(cfg, name, monkeypatch):
+    """The form large launches of 128-wide heads take (NV_ATTN_WAVES=0 forces it on small ones): workgroups of two
+    wavefronts in which a group keeps both only if it is at least 1.5 times as long as the launch's average group.
+    Same function as every fixed workgroup size, whichever way a group decides."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_ATTN_WAVES", "0")
+    q, kc, vc, ctx, tables = _paged_case(dt=DT[name], **cfg)
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, cfg["D"] ** -0.5)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5, num_splits=1)
+    OA.check_close(got, want, want_abs, "paged decode, adaptive wavefront count")
+    monkeypatch.setenv("NV_ATTN_WAVES", "2")
+    fixed = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), cfg["D"] ** -0.5, num_splits=1)
+    mean = sum(cfg["lens"]) / len(cfg["lens"])
+    for b, n in enumerate(cfg["lens"]):
+        if 2 * n >= 3 * mean:        # kept both wavefronts: the very same arithmetic as the fixed two-wavefront launch
+            assert torch.equal(got[b].cpu(), fixed[b].cpu()), f"row {b}"
+
+
+@pytest.mark.parametrize("lens", [[3000, 500], [1999, 1999], [96, 3000]])
+def test_paged_decode_adaptive_chunk_census(lens, monkeypatch):
+    """The census of test_paged_decode_chunk_census for the adaptive form: a group that keeps one wavefront walks all
+    of its chunks with it, a group that keeps two deals them round-robin; no chunk may be skipped or doubled."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_ATTN_WAVES", "0")
+    D, H, Hkv = 128, 28, 4
+    q, kc, vc, ctx, tables = _paged_case(B=2, H=H, Hkv=Hkv, D=D, bs=256, lens=lens, dt=torch.bfloat16, seed=lens[0])
+    q = (q * 0.25).to(torch.bfloat16)
+    vc.zero_()
+    for b, nb in enumerate(lens):
+        tok = torch.arange(nb)
+        for h in range(Hkv):
+            vc[tables[b, tok // 256].long(), tok % 256, h, (tok // 32) % D] = 1.0
+    want, want_abs = _decode_oracle(q, kc, vc, ctx, tables, D ** -0.5)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5, num_splits=1)
+    OA.check_close(got, want, want_abs, "chunk census, adaptive")
+    assert torch.allclose(got.float().cpu().sum(-1), torch.ones(2, H), atol=2e-2)
+
+
 def test_paged_decode_ignores_garbage_past_context():
     """Slots past the context length may hold NaN/Inf bit patterns (recycled blocks): they must not leak."""
     from byox_vllm_amd import kernels
