@@ -12,18 +12,23 @@ typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef f16_t f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Store of a kernel's result that the next launch of a chain reads.  NT = non-temporal: the line does not take room
-// in the memory-side cache that a small model's weights can otherwise keep from one decode step to the next.  The
-// choice is a template parameter of the kernels, made by their launchers from the process-wide result-store policy
-// (nv_set_result_policy): written as a run-time branch around the store it costs more than it gains (the compiler
-// merges `if (nt) nontemporal_store else store` into one plain store, and an inline-asm store in its place slowed the
-// step with the policy off by as much as the policy gains).
-template <bool NT, typename V>
+// Store of a kernel's result that the next launch of a chain reads.  WT = written through at device scope (sc1): the
+// line goes to the memory side while the kernel still runs instead of sitting dirty in the writing XCD's L2 until the
+// kernel ends, which is where a consumer on another XCD has to fetch it from anyway; and it leaves the L2 and the
+// memory-side cache to the weights.  Measured per decode step against plain stores: Qwen2-0.5B int4 -2.4 %, Qwen2-7B
+// int4 -2.4 %, 0.5B int8 -0.7 %; a non-temporal store (nt) in its place gains 1.6 % on the first and LOSES 1.3-1.8 % on
+// the others (the consumer then reads HBM), nt together with sc1 loses 6 %.  The choice is a template parameter of
+// the kernels, made by their launchers from the process-wide result-store policy (nv_set_result_policy): written as
+// a run-time branch around the store it costs every kernel about 0.1 us with the policy off.
+template <bool WT, typename V>
 __device__ __forceinline__ void out_store(V* p, V v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, p);
-  else *p = v;
+  static_assert(sizeof(V) == 16 || sizeof(V) == 8 || sizeof(V) == 4, "out_store: 4, 8 or 16 bytes");
+  if constexpr (!WT) *p = v;
+  else if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
-int nv_result_policy();   // 1: results are stored non-temporal (misc.hip)
+int nv_result_policy();   // 1: results are written through (misc.hip)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define NV_WAVE 64

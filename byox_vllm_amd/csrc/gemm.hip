@@ -40,7 +40,7 @@ struct GemmArgs {
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
   int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
-  int result_nt;   // 1: non-temporal result stores (quantised weights, epi 1 / 2 / 3): the result-store policy
+  int result_nt;   // 1: write-through result stores (epi 1 / 2 / 3): the result-store policy
 };
 void nv_gemm_launch_bf16(const GemmArgs& a);
 void nv_gemm_launch_f16(const GemmArgs& a);

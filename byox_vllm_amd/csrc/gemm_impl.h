@@ -76,7 +76,7 @@ constexpr int gemm_lds_bytes() {
 // stores of four lanes per row took the launch from 92 to 110 us (no write combining), 6 us per step more than the
 // 39 MB of cache the logits buffer occupies cost.
 template <typename T, int WFMT, int BM, int NTW, int EPI, bool STREAM = false, bool RNT = false>
-                                                            // RNT: results stored non-temporal (common.h out_store; EPI 1-3)
+                                                            // RNT: results written through (common.h out_store; EPI 1-3)
                                                             // EPI: 0 = store (+bias), 1 = silu(gate)*up, 2 = fp32 slab per K-split,
                                                             //      3 = q/k/v projection: +bias, head norm, RoPE, KV-cache store
                                                             //      4 = store + the sampler's per-part statistics (LM head)
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const uint16_t* __restrict__ 
 // workgroups for 256 CUs), ten tiles per workgroup fill the chip in one round (237).  The second k-step group takes
 // the column groups in reverse order, so each SIMD (wavefronts w and w + 4) carries 3 + 2 tiles.
 #define GEMM_MIXED_TILES 10
-template <typename T, int WFMT, int EPI>
+template <typename T, int WFMT, int EPI, bool RNT = false>
 __global__ __launch_bounds__(512) void gemm_mixed_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                          const void* __restrict__ w, const uint16_t* __restrict__ scales,
                                                          const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
@@ -593,10 +593,10 @@ __global__ __launch_bounds__(512) void gemm_mixed_kernel(const uint16_t* __restr
   const int kg = wave >> 2, wid = kg ? 3 - (wave & 3) : (wave & 3);
   const int first = blockIdx.x * GEMM_MIXED_TILES;
   if (wid < 2)
-    gemm_body<T, WFMT, 128, 3, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
+    gemm_body<T, WFMT, 128, 3, EPI, false, RNT>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
                                     SampleParts{}, lds_raw, wid, kg, first + 3 * wid);
   else
-    gemm_body<T, WFMT, 128, 2, EPI>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
+    gemm_body<T, WFMT, 128, 2, EPI, false, RNT>(x, x_stride, w, scales, bias, out, out_stride, partial, M, N, K, split_k, RopeArgs{},
                                     SampleParts{}, lds_raw, wid, kg, first + 6 + 2 * (wid - 2));
 }
 
@@ -635,7 +635,7 @@ struct GemmArgs {
   int mixed;       // 1: 128 rows x 160 columns per workgroup (gemm_mixed_kernel; quantised weights, epi 0..2)
   int wide;        // 1: the 32x32x16 kernel (int4, 128-row tiles, 192 columns per workgroup), gemm_wide.h
   int stream_once; // 1: non-temporal weight loads (streaming-layout weights, epi 0 / 4, one row tile)
-  int result_nt;   // 1: non-temporal result stores (quantised weights, epi 1 / 2 / 3): the result-store policy
+  int result_nt;   // 1: write-through result stores (epi 1 / 2 / 3): the result-store policy
 };
 #endif
 
@@ -656,15 +656,11 @@ static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 
 template <typename T, int WFMT, int NTW>
 static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
-  // the non-temporal result stores exist for the quantised formats only: a decoder whose weights fit the memory-side
-  // cache is a quantised one (dense models of that size are toys), and every instantiation costs build time
-  if constexpr (WFMT == NV_W_INT4 || WFMT == NV_W_INT8) {
-    if (a.result_nt && a.epi >= 1 && a.epi <= 3) {
-      if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1, false, true>(a, grid);
-      else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2, false, true>(a, grid);
-      else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3, false, true>(a, grid);
-      return;
-    }
+  if (a.result_nt && a.epi >= 1 && a.epi <= 3) {   // the result-store policy: the same kernels with write-through stores
+    if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1, false, true>(a, grid);
+    else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2, false, true>(a, grid);
+    else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3, false, true>(a, grid);
+    return;
   }
   if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
   else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
@@ -679,11 +675,13 @@ template <typename T, int WFMT>
 static void gemm_go_mixed(const GemmArgs& a) {
   const int ntiles = a.N / 16;
   dim3 grid((ntiles + GEMM_MIXED_TILES - 1) / GEMM_MIXED_TILES, (unsigned)((a.M + 127) / 128), a.split_k);
-#define GO(EPIV)                                                                                                 \
-  gemm_mixed_kernel<T, WFMT, EPIV><<<grid, dim3(512), 0, a.stream>>>(                                            \
+#define GO(EPIV, RNTV)                                                                                           \
+  gemm_mixed_kernel<T, WFMT, EPIV, RNTV><<<grid, dim3(512), 0, a.stream>>>(                                      \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,     \
       a.os, a.partial, a.M, a.N, a.K, a.split_k)
-  if (a.epi == 0) GO(0); else if (a.epi == 1) GO(1); else GO(2);
+  if (a.epi == 0) GO(0, false);
+  else if (a.epi == 1) { if (a.result_nt) GO(1, true); else GO(1, false); }
+  else { if (a.result_nt) GO(2, true); else GO(2, false); }
 #undef GO
 }
 

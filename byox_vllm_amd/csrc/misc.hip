@@ -21,9 +21,9 @@ extern "C" int nv_version(void) { return 100; }
 // in force at capture time.  One word, written by set-up code only.
 static int g_result_policy = 0;
 int nv_result_policy() { return g_result_policy; }
-extern "C" int nv_set_result_policy(int nontemporal) {
-  NV_CHECK_ARG(nontemporal == 0 || nontemporal == 1, "nv_set_result_policy: %d is neither 0 nor 1", nontemporal);
-  g_result_policy = nontemporal;
+extern "C" int nv_set_result_policy(int write_through) {
+  NV_CHECK_ARG(write_through == 0 || write_through == 1, "nv_set_result_policy: %d is neither 0 nor 1", write_through);
+  g_result_policy = write_through;
   return NV_OK;
 }
 extern "C" int nv_get_result_policy(void) { return g_result_policy; }

@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x4 round4(f32x4 v) {
 // first half (x1) and the matching four of the second half (x2), already rounded to the model dtype.
 // `row` = the head's place in the qkv buffer; write_v_row: value heads are written there too (they are not there yet).
 // Every lane of a head group must make the call (shuffles); lanes with live == false only take part in those.
-template <typename T, bool NT = false>   // NT: q/k/v rows and cache rows stored non-temporal (common.h out_store)
+template <typename T, bool NT = false>   // NT: q/k/v rows and cache rows written through (common.h out_store)
 __device__ __forceinline__ void rope_finish(f32x4 x1, f32x4 x2, const RopeArgs& ra, int hs, int64_t t, int sub,
                                             uint16_t* row, bool write_v_row, bool live) {
   const int D = ra.D, H = ra.H, Hkv = ra.Hkv, lph = D >> 3;

@@ -11,7 +11,7 @@
 #include "rope_common.h"
 #include "splitk.h"
 
-template <typename T, bool PARTIAL, bool NT>  // PARTIAL: the qkv rows exist only as split-K slabs; NT: common.h out_store
+template <typename T, bool PARTIAL, bool NT>  // PARTIAL: the qkv rows exist only as split-K slabs; NT: results written through, common.h out_store
 __global__ __launch_bounds__(256) void rope_kv_kernel(uint16_t* qkv, int64_t row_stride, RopeArgs ra, int64_t ntok,
                                                       const float* __restrict__ part, int nparts,
                                                       const uint16_t* __restrict__ bias) {

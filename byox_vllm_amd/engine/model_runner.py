@@ -97,6 +97,7 @@ class ModelRunner:
             self._load_weights()
             self.model.finalize(config.quantization)
             self.decode_result_policy = self._pick_decode_result_policy()
+            self.prefill_result_policy = int(os.environ.get("NV_RESULT_POLICY_PREFILL", "0"))
             self.sampler = Sampler(seed=config.seed)
             self._warmup_model()
             self._allocate_kv_cache()
@@ -123,21 +124,20 @@ class ModelRunner:
                 self.shm = SharedMemory(name=shm_name)
                 self._loop()
 
-    # Decoder weights up to this size are taken to stay in the MI355X's 256 MB memory-side cache between decode steps,
-    # provided nothing else of a step allocates there: K/V and the LM head are streamed with non-temporal loads by the
-    # library's own choice, and the activations with non-temporal stores under the policy picked here.
-    CACHE_RESIDENT_WEIGHT_BYTES = 192 << 20
-
     def _pick_decode_result_policy(self) -> int:
-        """Non-temporal result stores for DECODE steps of a model whose decoder weights fit the memory-side cache
-        (Qwen2-0.5B in int4: 179 MB, measured 1.6 % per step); 0 otherwise (larger models lose 1-2 % with them, and a
-        prefill's results are too large to gain).  NV_RESULT_POLICY=0/1 overrides the choice."""
-        from byox_vllm_amd.layers.linear import LinearBase
-        forced = os.environ.get("NV_RESULT_POLICY")
-        if forced is not None:
-            return int(forced)
-        decoder = sum(m.packed.nbytes for m in self.model.modules() if isinstance(m, LinearBase))
-        return 1 if decoder <= self.CACHE_RESIDENT_WEIGHT_BYTES else 0
+        """Write-through result stores (nv_set_result_policy) for DECODE steps: what a launch hands to the next one
+        (norm rows, residual rows, SiLU*up rows, split-K slabs, q/k/v and KV-cache rows) goes to the memory side while
+        the kernel still runs, which is where a consumer on another XCD finds it.  Measured per decode step:
+        Qwen2-0.5B int4 -2.4 %, Qwen2-7B int4 -2.4 %, 0.5B int8 and bf16 -0.7 %, Qwen3-0.6B bf16 -0.9 %.  Prefill steps
+        keep plain stores (their results are large: 8 x 1024 tokens -1 %, 16 x 2048 -5 % with the policy).
+        Decode steps of more than RESULT_WT_MAX_ROWS sequences keep plain stores too (Qwen2-7B at 512 rows: +0.5 %).
+        NV_RESULT_POLICY=0/1 overrides the choice for decode, NV_RESULT_POLICY_PREFILL=1 switches it on for prefill."""
+        return int(os.environ.get("NV_RESULT_POLICY", "1"))
+
+    RESULT_WT_MAX_ROWS = 256
+
+    def _decode_policy_for(self, rows: int) -> int:
+        return self.decode_result_policy if rows <= self.RESULT_WT_MAX_ROWS else 0
 
     def _release_after_failed_init(self) -> None:
         """A constructor that raised half-way (an uncapturable collective, out of memory) gives back what it had
@@ -448,9 +448,10 @@ class ModelRunner:
         if is_prefill or self.enforce_eager or bs > self.max_graph_bs or self.graph_has_head:
             if not is_prefill:
                 self._set_decode_splits(bs)
-                with kernels.result_policy(self.decode_result_policy):
+                with kernels.result_policy(self._decode_policy_for(bs)):
                     return self.model.compute_logits(self.model(input_ids, positions))
-            return self.model.compute_logits(self.model(input_ids, positions))
+            with kernels.result_policy(self.prefill_result_policy):
+                return self.model.compute_logits(self.model(input_ids, positions))
         context = get_context()
         padded = next(x for x in self.graph_bs if x >= bs)
         g = self.graph_vars
@@ -564,7 +565,7 @@ class ModelRunner:
             words = 2 + bs * (5 + max_blocks) if self.graph_has_head else 0
             g["padded_bs"] = bs
             self._host_stage_np[:2] = 0          # warm-up and capture run on an empty step (all rows padding)
-            with kernels.result_policy(self.decode_result_policy):
+            with kernels.result_policy(self._decode_policy_for(bs)):
                 forward_rows(bs, words)          # warm-up: sizes every workspace before anything is captured
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
@@ -580,3 +581,4 @@ class ModelRunner:
     max_graph_bs = 0
     graph_has_head = False
     decode_result_policy = 0
+    prefill_result_policy = 0

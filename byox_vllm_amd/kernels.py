@@ -48,12 +48,13 @@ class PendingReduce:
 
 
 class result_policy:
-    """``with result_policy(1):`` — launches made inside store the results the next launch reads non-temporal
-    (include/nv_hip.h nv_set_result_policy; a captured launch keeps the policy it was captured under).  The setting is
-    one word per process, so it is restored on the way out: runners with different policies can share a process."""
+    """``with result_policy(1):`` — launches made inside write the results the next launch reads through to the memory
+    side (include/nv_hip.h nv_set_result_policy; a captured launch keeps the policy it was captured under).  The
+    setting is one word per process, so it is restored on the way out: runners with different policies can share a
+    process."""
 
-    def __init__(self, nontemporal: int):
-        self.mask = int(nontemporal)
+    def __init__(self, write_through: int):
+        self.mask = int(write_through)
 
     def __enter__(self):
         self.previous = lib().nv_get_result_policy()

@@ -108,14 +108,14 @@ size_t nv_paged_attn_decode_workspace_bytes(int B, int H, int D, int num_splits)
 int nv_paged_attn_decode_pick_splits(int B, int Hkv, int max_context);
 /* Cache policy of results that the NEXT launch of a chain reads (no counterpart in the reference, which leaves cache
  * policy to PyTorch's kernels).  1: the normalised and residual rows of nv_add_rmsnorm(_splitk) / nv_rmsnorm at model
- * width, the SiLU(gate)*up rows and split-K slabs of nv_gemm on quantised weights, and the q/k/v rows with their
- * KV-cache rows of nv_rope_kv_store(_splitk) / nv_gemm_rope_kv_store are written with non-temporal stores by every
- * later launch of this process (a captured launch keeps the policy it was captured under); 0, the default, stores
- * normally.  For a model whose decoder weights fit the 256 MB memory-side cache of the MI355X next to a step's
- * activations, keeping the activations out of that cache leaves the weights resident from one decode step to the
- * next; for larger models and for prefill it costs 1-4 %, so the caller sets it per step kind
- * (byox_vllm_amd/engine/model_runner.py).  The results are the same bits either way. */
-int nv_set_result_policy(int nontemporal);
+ * width, the SiLU(gate)*up rows and split-K slabs of nv_gemm, and the q/k/v rows with their KV-cache rows of
+ * nv_rope_kv_store(_splitk) / nv_gemm_rope_kv_store are written through to the memory side (device-scope stores) by
+ * every later launch of this process (a captured launch keeps the policy it was captured under); 0, the default,
+ * stores normally.  On the 8-XCD MI355X a consumer kernel fetches its producer's results from the memory side
+ * anyway; writing them through while the producer still runs shortens that hand-over (decode steps 0.7-2.4 % faster),
+ * while the large results of a prefill are better left to the L2 (1-5 % slower with the policy), so the caller sets it
+ * per step kind (byox_vllm_amd/engine/model_runner.py).  The results are the same bits either way. */
+int nv_set_result_policy(int write_through);
 int nv_get_result_policy(void);
 /* Revision name of the decode kernel's memory access pattern (no counterpart in the reference: flash-attn is a
  * binary there).  Hardware-counter collections record it so that a measurement taken on another revision of the

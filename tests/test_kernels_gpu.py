@@ -1089,7 +1089,7 @@ def test_bad_arguments_are_rejected_not_launched():
         kernels.rms_norm(torch.zeros(4, 128, dtype=torch.bfloat16), torch.ones(128, dtype=torch.bfloat16), 1e-6)
 
 
-@pytest.mark.parametrize("fmt", ["w4a16", "w8a16"])
+@pytest.mark.parametrize("fmt", ["w4a16", "w8a16", "tiled"])
 def test_result_store_policy_changes_no_bit(fmt):
     """nv_set_result_policy only picks the cache policy of the stores: normalised rows, residual rows, SiLU(gate)*up
     rows, split-K slabs (through the norm that sums them) and the q/k/v + cache rows of both RoPE forms are the same
@@ -1103,9 +1103,10 @@ def test_result_store_policy_changes_no_bit(fmt):
     x = dev(torch.randn(M, K, generator=g).to(dt))
     res = dev(torch.randn(M, K, generator=g).to(dt))
     nw = dev((1 + 0.1 * torch.randn(K, generator=g)).to(dt))
-    w_gu = LinearWeight.make(dev(interleave_gate_up((torch.randn(2 * I, K, generator=g) * 0.05).to(dt))), fmt)
-    w_o = LinearWeight.make(dev((torch.randn(K, K, generator=g) * 0.05).to(dt)), fmt)
-    w_qkv = LinearWeight.make(dev((torch.randn((H + 2 * Hkv) * d, K, generator=g) * 0.05).to(dt)), fmt)
+    make = (lambda w: LinearWeight.dense_tiled(w)) if fmt == "tiled" else (lambda w: LinearWeight.make(w, fmt))
+    w_gu = make(dev(interleave_gate_up((torch.randn(2 * I, K, generator=g) * 0.05).to(dt))))
+    w_o = make(dev((torch.randn(K, K, generator=g) * 0.05).to(dt)))
+    w_qkv = make(dev((torch.randn((H + 2 * Hkv) * d, K, generator=g) * 0.05).to(dt)))
     pos = dev(torch.randint(0, 200, (M,), generator=g))
     slots = dev(torch.randperm(nb * bs, generator=g)[:M].to(torch.int32))
     table = dev(L.build_cos_sin_cache(d, 256, 1e6))

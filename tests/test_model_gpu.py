@@ -396,8 +396,8 @@ def test_graph_replay_equals_eager(golden):
 
 @pytest.mark.parametrize("eager", [True, False])
 def test_result_store_policy_changes_no_token_and_no_logit(golden, monkeypatch, eager):
-    """The tiny model's weights fit the memory-side cache, so its decode steps run under the non-temporal result-store
-    policy; forced off (NV_RESULT_POLICY=0) the same steps give the same tokens and bit-identical KV-cache rows."""
+    """Decode steps run under the write-through result-store policy; forced off (NV_RESULT_POLICY=0) the same steps give
+    the same tokens and bit-identical KV-cache rows."""
     from byox_vllm_amd._C import lib
     from byox_vllm_amd.engine.sequence import Sequence
     from byox_vllm_amd.sampling_params import SamplingParams
