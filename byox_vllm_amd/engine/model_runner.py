@@ -130,14 +130,18 @@ class ModelRunner:
         the kernel still runs, which is where a consumer on another XCD finds it.  Measured per decode step:
         Qwen2-0.5B int4 -2.4 %, Qwen2-7B int4 -2.4 %, 0.5B int8 and bf16 -0.7 %, Qwen3-0.6B bf16 -0.9 %.  Prefill steps
         keep plain stores (their results are large: 8 x 1024 tokens -1 %, 16 x 2048 -5 % with the policy).
-        Decode steps of more than RESULT_WT_MAX_ROWS sequences keep plain stores too (Qwen2-7B at 512 rows: +0.5 %).
+        Decode steps outside RESULT_WT_ROWS keep plain stores too: with few rows the results are a few KB and waiting
+        for their write-through costs more than the L2 write-back it saves (Qwen2-0.5B int4, policy on against off:
+        batch 1 +3.4 %, 4 +1.5 %, 16 +2.1 %, 32 +0.2 %, 64 +0.6 % / int8 -0.7 %, 128 -1.9 %), with 512 rows they are
+        megabytes (Qwen2-7B: +0.5 %).
         NV_RESULT_POLICY=0/1 overrides the choice for decode, NV_RESULT_POLICY_PREFILL=1 switches it on for prefill."""
         return int(os.environ.get("NV_RESULT_POLICY", "1"))
 
-    RESULT_WT_MAX_ROWS = 256
+    RESULT_WT_ROWS = (64, 256)
 
     def _decode_policy_for(self, rows: int) -> int:
-        return self.decode_result_policy if rows <= self.RESULT_WT_MAX_ROWS else 0
+        lo, hi = self.RESULT_WT_ROWS
+        return self.decode_result_policy if lo <= rows <= hi else 0
 
     def _release_after_failed_init(self) -> None:
         """A constructor that raised half-way (an uncapturable collective, out of memory) gives back what it had

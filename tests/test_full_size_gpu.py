@@ -82,8 +82,12 @@ def make_seqs(batch, order=None, temperature=0.0):
 
 
 def test_result_store_policy_is_on_for_decode_only(full):
-    """Decode steps write their hand-over results through (eager and captured runner alike); prefill keeps plain stores."""
-    assert all(r.decode_result_policy == 1 and r.prefill_result_policy == 0 for r in full.runners.values()), full.name
+    """Decode steps of 64 to 256 rows write their hand-over results through (eager and captured runner alike); smaller
+    and larger steps and prefill keep plain stores."""
+    for r in full.runners.values():
+        assert r.decode_result_policy == 1 and r.prefill_result_policy == 0, full.name
+        assert r._decode_policy_for(full.batch) == (1 if 64 <= full.batch <= 256 else 0)
+        assert r._decode_policy_for(1) == 0 and r._decode_policy_for(512) == 0
 
 
 def test_graph_and_eager_agree_and_rows_permute(full):

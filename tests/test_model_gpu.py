@@ -401,8 +401,12 @@ def test_result_store_policy_changes_no_token_and_no_logit(golden, monkeypatch, 
     from byox_vllm_amd._C import lib
     from byox_vllm_amd.engine.sequence import Sequence
     from byox_vllm_amd.sampling_params import SamplingParams
+    from byox_vllm_amd.engine.model_runner import ModelRunner
     _, _, weights = _golden_weights(golden, "qwen2")
     cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    lo, hi = ModelRunner.RESULT_WT_ROWS
+    assert lo > 1 and hi < 512          # tiny and very large steps keep plain stores: this test's three rows would too
+    monkeypatch.setattr(ModelRunner, "RESULT_WT_ROWS", (1, hi))
     outs = []
     for forced in (None, "0"):
         if forced is None:
@@ -411,6 +415,7 @@ def test_result_store_policy_changes_no_token_and_no_logit(golden, monkeypatch, 
             monkeypatch.setenv("NV_RESULT_POLICY", forced)
         runner = make_runner(cfg, weights, enforce_eager=eager, max_num_seqs=8)
         assert runner.decode_result_policy == (1 if forced is None else 0)
+        assert runner._decode_policy_for(3) == runner.decode_result_policy
         rng = np.random.RandomState(11)
         seqs = []
         for i, n in enumerate((7, 18, 31)):
