@@ -69,16 +69,15 @@ def test_fuzz_prefill_attention(seed):
     OA.check_close(got, want, want_abs, f"fuzz prefill seed {seed}")
 
 
-@pytest.mark.parametrize("seed", range(10))
-def test_fuzz_paged_decode_attention(seed):
-    from byox_vllm_amd import kernels
+def _fuzz_decode_case(seed, D=None, max_batch=9):
     rng = np.random.RandomState(500 + seed)
     name = "bf16" if seed % 2 else "fp16"
     dt = DT[name]
     H, Hkv = HEADS[seed % len(HEADS)]
-    D = 64 if seed % 4 < 2 else 128
+    if D is None:
+        D = 64 if seed % 4 < 2 else 128
     bs = int(rng.choice([16, 48, 256]))
-    B = int(rng.randint(1, 9))
+    B = int(rng.randint(1, max_batch))
     lens = [0 if rng.rand() < 0.1 else _len(rng) for _ in range(B)]
     g = torch.Generator().manual_seed(seed)
     nblk = sum(-(-n // bs) for n in lens) + 2
@@ -98,9 +97,27 @@ def test_fuzz_paged_decode_attention(seed):
     ctx = torch.tensor(lens, dtype=torch.int32)
     want = OA.paged_attn_decode(q, kc, vc, ctx, tables, D ** -0.5)
     want_abs = OA.paged_attn_decode(q, kc, vc.abs(), ctx, tables, D ** -0.5)
+    return rng, D, lens, q, kc, vc, ctx, tables, want, want_abs
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_paged_decode_attention(seed):
+    from byox_vllm_amd import kernels
+    rng, D, lens, q, kc, vc, ctx, tables, want, want_abs = _fuzz_decode_case(seed)
     for splits in (1, int(rng.randint(2, 6))):
         got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5, num_splits=splits)
         OA.check_close(got, want, want_abs, f"fuzz decode seed {seed} splits {splits} lens {lens}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_paged_decode_adaptive_wavefronts(seed, monkeypatch):
+    """The adaptive form of the decode kernel (128-wide heads; a group keeps one or both wavefronts by its length
+    against the launch's average) on ragged batches with empty rows and junk behind the contexts."""
+    from byox_vllm_amd import kernels
+    monkeypatch.setenv("NV_ATTN_WAVES", "0")
+    rng, D, lens, q, kc, vc, ctx, tables, want, want_abs = _fuzz_decode_case(seed, D=128, max_batch=17)
+    got = kernels.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(tables), D ** -0.5, num_splits=1)
+    OA.check_close(got, want, want_abs, f"fuzz decode, adaptive, seed {seed} lens {lens}")
 
 
 @pytest.mark.parametrize("seed", range(16))
