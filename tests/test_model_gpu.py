@@ -265,6 +265,40 @@ def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
                                 expect_exact=True, label=f"metric geometry tp{tp}")
 
 
+@pytest.mark.parametrize("tp,collectives", [(2, "gloo"), (2, "xgmi-graph"), (4, "xgmi-graph")])
+def test_engine_tensor_parallel_under_the_result_store_policy(tp, collectives, monkeypatch):
+    """bench.py --gpus N runs the tensor-parallel step at 128 rows, where every rank writes its hand-over results
+    through (the result-store policy); the engine tests above run a handful of rows, where the policy is off.  Here
+    the window is opened to small steps (NV_RESULT_POLICY_ROWS, read by the worker processes too), so the sharded
+    GEMMs' slabs, the fused all-reduce that reads them and the q/k/v and norm rows all take the write-through stores:
+    tokens identical to the oracle's."""
+    from types import SimpleNamespace
+
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    monkeypatch.setenv("NV_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("NV_RESULT_POLICY_ROWS", "1,256")
+    get_rope.cache_clear()
+    cfg = SimpleNamespace(vocab_size=1024, hidden_size=896, intermediate_size=4864, num_hidden_layers=2,
+                          num_attention_heads=14, num_key_value_heads=2, head_dim=64, max_position_embeddings=128,
+                          rms_norm_eps=1e-6, hidden_act="silu", attention_bias=True, rope_theta=1000000.0,
+                          rope_scaling=None, tie_word_embeddings=True, dtype=torch.bfloat16)
+    weights = OM.random_weights(cfg, seed=3)
+    rng = np.random.RandomState(17)
+    prompts = [rng.randint(0, 1024, size=n).tolist() for n in (9, 30, 17)]
+    llm = LLM("synthetic", hf_config=cfg, state_dict=weights, quantization="w4a16", kvcache_block_size=BS,
+              num_kvcache_blocks=16, enforce_eager=collectives != "xgmi-graph", max_model_len=128,
+              max_num_batched_tokens=256, max_num_seqs=8, tensor_parallel_size=tp, xgmi_allreduce=collectives != "gloo")
+    try:
+        assert llm.model_runner._decode_policy_for(3) == 1
+        outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), use_tqdm=False)
+    finally:
+        llm._exit()
+    got = [o["token_ids"] for o in outs]
+    check_tokens_against_oracle(cfg, OM.fake_quantize(weights, 4), prompts, got, block_size=BS, num_blocks=16,
+                                expect_exact=True, label=f"metric geometry tp{tp} {collectives}, write-through results")
+
+
 def test_engine_tensor_parallel_qwen2_7b_geometry_on_8_ranks(monkeypatch):
     """BASELINE configuration 5's shards at their own shapes: one Qwen2-7B layer (28 query / 4 KV heads of 128, hidden
     3584, intermediate 18944 = 148 K-blocks dealt 19,19,19,19,18,18,18,18, int4) over 8 ranks sharing the GPU, a small
