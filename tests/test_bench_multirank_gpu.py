@@ -22,8 +22,10 @@ def _bench(extra, env_extra=None, launcher=False, expect_failure=False):
     if launcher:      # the round driver's form: an external launcher, one process per rank
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", "29533"]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-            "--workload", "qwen2-0.5b-fp16-b1-s128"] + extra
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    if "--workload" not in extra:
+        cmd += ["--workload", "qwen2-0.5b-fp16-b1-s128"]
+    cmd += extra
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert (out.returncode != 0) == expect_failure, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -76,3 +78,16 @@ def test_bench_line_survives_a_tensor_parallel_leg_that_takes_the_job_down(hook)
     d = _bench([], env_extra={hook: "1", "NV_BENCH_LEG_DEADLINE": "20"}, expect_failure=True)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert "keeper process" in d["tp_error"] and d["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_on_the_metric_workload():
+    """The configuration a multi-GPU scaling run takes by default, at its real size: Qwen2-0.5B int4, 128 rows, one
+    model over two ranks, the decode graph captured with the fused all-reduce inside and the hand-over results written
+    through (the result-store policy applies at 128 rows).  Two ranks share this GPU, so the process group is gloo."""
+    d = _bench(["--workload", "qwen2-0.5b-w4a16-b128-s1024", "--allreduce", "xgmi", "--single-leg", "--no-replicas"])
+    assert d["config"]["workload"] == "qwen2-0.5b-w4a16-b128-s1024" and d["config"]["parallelism"] == "tp2"
+    assert d["graph_captured"] is True and d["allreduce"].startswith("nv_allreduce_add_rmsnorm")
+    assert d["value"] > 0 and d["tp_error"] is None and d["scaling"] == "strong"
+    # each rank holds one of the two KV heads: a launch reads K and V rows of 64 elements for every cached token
+    tokens = d["roofline"]["bytes_per_launch"] / (2 * 64 * 2)
+    assert 128 * 1024 <= tokens <= 128 * 1100 and d["roofline"]["frac"] > 0
