@@ -1,7 +1,12 @@
-// bf16 instantiations of the decode GEMM.
+// bf16 instantiations of the decode GEMM: the dense formats with plain stores.  The quantised formats are in
+// gemm_bf16_q.hip, the write-through epilogues of both in gemm_bf16_wt.hip: three units that compile side by side.
 #include "gemm_impl.h"
-#include "gemm_wide.h"
 
-void nv_gemm_launch_bf16(const GemmArgs& a) { gemm_dispatch<bf16_t>(a); }
+void nv_gemm_launch_wt_bf16(const GemmArgs& a);
+void nv_gemm_launch_q_bf16(const GemmArgs& a);
+void nv_gemm_launch_bf16(const GemmArgs& a) {
+  if (gemm_wants_wt(a)) nv_gemm_launch_wt_bf16(a);
+  else if (gemm_is_quant(a)) nv_gemm_launch_q_bf16(a);
+  else gemm_dispatch<bf16_t, false, true, false>(a);
+}
 void nv_gemm_reduce_bf16(const GemmArgs& a) { reduce_dispatch<bf16_t>(a); }
-void nv_gemm_wide_launch_bf16(const GemmArgs& a) { gemm_wide_dispatch<bf16_t>(a); }

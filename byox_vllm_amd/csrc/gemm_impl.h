@@ -654,24 +654,34 @@ static void gemm_go_bm(const GemmArgs& a, dim3 grid) {
 #undef GO
 }
 
-template <typename T, int WFMT, int NTW>
+// WT selects which half of the instantiations a translation unit holds: the write-through epilogues of the result-store
+// policy (epi 1-3 with a.result_nt set) live in gemm_<dtype>_wt.hip, everything else in gemm_<dtype>.hip, so the two
+// halves compile side by side.  gemm_wants_wt() is the routing rule both sides agree on.
+static inline bool gemm_wants_wt(const GemmArgs& a) {
+  if (!a.result_nt || a.wide) return false;
+  if (a.mixed) return a.epi == 1 || a.epi == 2;
+  if (a.wfmt == NV_W_DENSE_TILED && a.stream_once && (a.epi == 0 || a.epi == 4)) return false;
+  return a.epi == 1 || a.epi == 2 || (a.epi == 3 && a.ntw <= 2);
+}
+
+template <typename T, int WFMT, int NTW, bool WT>
 static void gemm_go_epi(const GemmArgs& a, dim3 grid) {
-  if (a.result_nt && a.epi >= 1 && a.epi <= 3) {   // the result-store policy: the same kernels with write-through stores
+  if constexpr (WT) {   // the result-store policy: the same kernels with write-through stores
     if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1, false, true>(a, grid);
     else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2, false, true>(a, grid);
     else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3, false, true>(a, grid);
-    return;
+  } else {
+    if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
+    else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
+    else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
+    else if (a.epi == 4) {   // the LM head is never quantised
+      if constexpr (WFMT == NV_W_DENSE || WFMT == NV_W_DENSE_TILED) gemm_go_bm<T, WFMT, NTW, 4>(a, grid);
+    }
+    else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3>(a, grid);   // a head is 64 or 128 columns
   }
-  if (a.epi == 0) gemm_go_bm<T, WFMT, NTW, 0>(a, grid);
-  else if (a.epi == 1) gemm_go_bm<T, WFMT, NTW, 1>(a, grid);
-  else if (a.epi == 2) gemm_go_bm<T, WFMT, NTW, 2>(a, grid);
-  else if (a.epi == 4) {   // the LM head is never quantised
-    if constexpr (WFMT == NV_W_DENSE || WFMT == NV_W_DENSE_TILED) gemm_go_bm<T, WFMT, NTW, 4>(a, grid);
-  }
-  else if constexpr (NTW <= 2) gemm_go_bm<T, WFMT, NTW, 3>(a, grid);   // a head is 64 or 128 columns
 }
 
-template <typename T, int WFMT>
+template <typename T, int WFMT, bool WT>
 static void gemm_go_mixed(const GemmArgs& a) {
   const int ntiles = a.N / 16;
   dim3 grid((ntiles + GEMM_MIXED_TILES - 1) / GEMM_MIXED_TILES, (unsigned)((a.M + 127) / 128), a.split_k);
@@ -679,37 +689,59 @@ static void gemm_go_mixed(const GemmArgs& a) {
   gemm_mixed_kernel<T, WFMT, EPIV, RNTV><<<grid, dim3(512), 0, a.stream>>>(                                      \
       (const uint16_t*)a.x, a.xs, a.w, (const uint16_t*)a.scales, (const uint16_t*)a.bias, (uint16_t*)a.out,     \
       a.os, a.partial, a.M, a.N, a.K, a.split_k)
-  if (a.epi == 0) GO(0, false);
-  else if (a.epi == 1) { if (a.result_nt) GO(1, true); else GO(1, false); }
-  else { if (a.result_nt) GO(2, true); else GO(2, false); }
+  if constexpr (WT) {
+    if (a.epi == 1) GO(1, true); else GO(2, true);
+  } else {
+    if (a.epi == 0) GO(0, false); else if (a.epi == 1) GO(1, false); else GO(2, false);
+  }
 #undef GO
 }
 
 // One dtype's instantiations: dense takes 1 or 2 tiles per wavefront (16 raw registers per tile), quantised 1 or 3.
-template <typename T>
+// QUANT selects the other split of a dtype's plain instantiations: the quantised formats (int4 / int8, the 160-column
+// kernel) live in gemm_<dtype>_q.hip, the dense ones in gemm_<dtype>.hip.  The write-through unit holds both.
+static inline bool gemm_is_quant(const GemmArgs& a) {
+  return a.mixed || a.wfmt == NV_W_INT8 || a.wfmt == NV_W_INT4;
+}
+
+template <typename T, bool WT, bool DENSE_PART = true, bool QUANT_PART = true>
 static void gemm_dispatch(const GemmArgs& a) {
-  if (a.mixed) {
-    if (a.wfmt == NV_W_INT8) gemm_go_mixed<T, NV_W_INT8>(a); else gemm_go_mixed<T, NV_W_INT4>(a);
-    return;
+  if constexpr (QUANT_PART) {
+    if (a.mixed) {
+      if (a.wfmt == NV_W_INT8) gemm_go_mixed<T, NV_W_INT8, WT>(a); else gemm_go_mixed<T, NV_W_INT4, WT>(a);
+      return;
+    }
   }
   const int ntiles = a.N / 16;
   const int per_block = 4 * a.ntw;
   dim3 grid((ntiles + per_block - 1) / per_block, (unsigned)((a.M + a.bm - 1) / a.bm), a.split_k);
-  if (a.wfmt == NV_W_DENSE) {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2>(a, grid);
-  } else if (a.wfmt == NV_W_DENSE_TILED && a.stream_once && (a.epi == 0 || a.epi == 4)) {
-    if (a.epi == 4) { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 4, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 4, true>(a, grid); }
-    else            { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 0, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 0, true>(a, grid); }
-  } else if (a.wfmt == NV_W_DENSE_TILED) {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE_TILED, 1>(a, grid); else gemm_go_epi<T, NV_W_DENSE_TILED, 2>(a, grid);
-  } else if (a.wfmt == NV_W_INT8) {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1>(a, grid);
-    else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT8, 2>(a, grid);
-    else gemm_go_epi<T, NV_W_INT8, 3>(a, grid);
-  } else {
-    if (a.ntw == 1) gemm_go_epi<T, NV_W_INT4, 1>(a, grid);
-    else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT4, 2>(a, grid);
-    else gemm_go_epi<T, NV_W_INT4, 3>(a, grid);
+  if constexpr (DENSE_PART) {
+    if (a.wfmt == NV_W_DENSE) {
+      if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE, 1, WT>(a, grid); else gemm_go_epi<T, NV_W_DENSE, 2, WT>(a, grid);
+      return;
+    }
+    if constexpr (!WT) {
+      if (a.wfmt == NV_W_DENSE_TILED && a.stream_once && (a.epi == 0 || a.epi == 4)) {
+        if (a.epi == 4) { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 4, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 4, true>(a, grid); }
+        else            { if (a.ntw == 1) gemm_go_bm<T, NV_W_DENSE_TILED, 1, 0, true>(a, grid); else gemm_go_bm<T, NV_W_DENSE_TILED, 2, 0, true>(a, grid); }
+        return;
+      }
+    }
+    if (a.wfmt == NV_W_DENSE_TILED) {
+      if (a.ntw == 1) gemm_go_epi<T, NV_W_DENSE_TILED, 1, WT>(a, grid); else gemm_go_epi<T, NV_W_DENSE_TILED, 2, WT>(a, grid);
+      return;
+    }
+  }
+  if constexpr (QUANT_PART) {
+    if (a.wfmt == NV_W_INT8) {
+      if (a.ntw == 1) gemm_go_epi<T, NV_W_INT8, 1, WT>(a, grid);
+      else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT8, 2, WT>(a, grid);
+      else gemm_go_epi<T, NV_W_INT8, 3, WT>(a, grid);
+    } else if (a.wfmt == NV_W_INT4) {
+      if (a.ntw == 1) gemm_go_epi<T, NV_W_INT4, 1, WT>(a, grid);
+      else if (a.ntw == 2) gemm_go_epi<T, NV_W_INT4, 2, WT>(a, grid);
+      else gemm_go_epi<T, NV_W_INT4, 3, WT>(a, grid);
+    }
   }
 }
 

@@ -1,6 +1,6 @@
 """Build a measurement variant of the library: python scripts/build_variant.py NAME SOURCE[,SOURCE...] -DFLAG[=V] ...
 
-The named csrc sources (e.g. attn, gemm_bf16) are recompiled with the extra -D flags into objects under /tmp and linked
+The named csrc sources (e.g. attn, or gemm_bf16,gemm_bf16_q,gemm_bf16_wt for every bf16 GEMM) are recompiled with the extra -D flags into objects under /tmp and linked
 with the in-tree objects of all other sources into byox_vllm_amd/abl_NAME.so (git-ignored; it travels to the GPU box).
 Select it at run time with NV_HIP_LIB=byox_vllm_amd/abl_NAME.so, so one GPU call can time several variants of a
 kernel against the shipped build inside the same process environment.
