@@ -115,6 +115,19 @@ static int pick_ntw(int64_t M, int N, int K, int wfmt, int split_k, bool slabs) 
 extern "C" int nv_gemm_pick_split_k(int64_t M, int N, int K, int wfmt) {
   if (M <= 0 || N <= 0 || K < GEMM_BK) return 1;
   const int max_ntw = unquantised(wfmt) ? 2 : 3, nkb = K / GEMM_BK;
+  if (const char* e = getenv("NV_GEMM_SPLIT_K")) {   // measurement aid: "K:N:split[,K:N:split...]" forces those shapes' split
+    for (const char* p = e; *p;) {
+      char* end;
+      const long k = strtol(p, &end, 10);
+      if (*end != ':') break;
+      const long n = strtol(end + 1, &end, 10);
+      if (*end != ':') break;
+      const long sp = strtol(end + 1, &end, 10);
+      if (k == K && n == N && sp >= 1 && sp <= nkb) return (int)sp;
+      if (*end != ',') break;
+      p = end + 1;
+    }
+  }
   int best = 1;
   double best_us = 1e30;
   for (int split = 1; split <= nkb && split <= 32; ++split) {
