@@ -530,6 +530,9 @@ def main():
             "config": {"workload": args.workload, "geometry": model_name, "weight_format": quantization or dtype_name,
                        "batch_per_replica": batch, "context": context, "kv_block_size": block_size,
                        "parallelism": f"{'tp' if tp_now > 1 else 'dp'}{world}", "graph": graph_captured,
+                       # single-rank graph steps: step N+1 is launched as soon as step N's tokens are on the host,
+                       # before they are returned (K graph executions fall into the K timed steps either way)
+                       "run_ahead": bool(runner.run_ahead and graph_captured and tp_now == 1 and runner.graph_has_head),
                        "step": "ModelRunner.run decode: host prepare + hipGraph forward + LM head + sampler + D2H"},
             "ranks": world,
             # ranks that talk through RCCL: 0 when the job's process group is a rehearsal backend or there is one rank

@@ -564,6 +564,11 @@ __global__ __launch_bounds__(256) void stage_packed_kernel(const int32_t* __rest
     bs = p[0];
     bt_cols = p[1];
     p += 2;
+    // NV_STAGE_STEP_BACK: the previous launch's step was thrown away by the host, its count is taken back first
+    if (bt_cols >= 0 && (bt_cols & NV_STAGE_STEP_BACK)) {
+      bt_cols &= ~NV_STAGE_STEP_BACK;
+      if (tid == 0 && step_counter) step_counter[0] -= 1;
+    }
     const bool advance = prev_tokens != nullptr && bt_cols >= 0 && (bt_cols & NV_STAGE_ADVANCE);
     bs = bs < 0 ? 0 : (bs > padded ? padded : bs);
     if (advance) {

@@ -50,6 +50,8 @@ class ModelRunner:
             and not self.use_xgmi)
         self.world_size = config.tensor_parallel_size
         self.device_bookkeeping = os.environ.get("NV_DEVICE_BOOKKEEPING", "1") != "0"
+        # launch the next decode step before the caller asks for it, whenever no other next step is possible
+        self.run_ahead = self.device_bookkeeping and os.environ.get("NV_RUN_AHEAD", "1") != "0"
         self.spin_wait = os.environ.get("NV_SPIN_WAIT", "1") != "0"
         self.rank = rank
         self.event = event
@@ -230,9 +232,9 @@ class ModelRunner:
             dist.barrier()
             if self.rank == 0:
                 self.shm.unlink()
+        torch.cuda.synchronize()              # a step launched ahead may still be running: no graph is dropped under it
         if not self.enforce_eager:
             self.graphs, self.graph_pool = {}, None
-        torch.cuda.synchronize()
         if self.comm is not None:
             from byox_vllm_amd.layers.linear import set_comm
             if self.world_size > 1 and dist.is_initialized():
@@ -248,6 +250,7 @@ class ModelRunner:
         if (not is_prefill and not self.enforce_eager and self.world_size == 1
                 and 0 < len(seqs) <= self.max_graph_bs and self.graph_has_head):
             return self._run_decode_graph(seqs)
+        self._drop_step_ahead()
         input_ids, positions = self._prepare_prefill(seqs) if is_prefill else self._prepare_decode(seqs)
         temperatures = self._prepare_sample(seqs) if self.rank == 0 else None
         logits = self._run_model(input_ids, positions, is_prefill)
@@ -259,26 +262,94 @@ class ModelRunner:
     def _run_decode_graph(self, seqs: list[Sequence]) -> list[int]:
         """Single-rank decode fast path: the step's integers (the values _prepare_decode, _prepare_block_tables and
         _prepare_sample would produce) go to the device as ONE packed buffer; the replayed graph runs staging ->
-        forward -> LM head -> sampler; the only host sync is reading the token ids back."""
+        forward -> LM head -> sampler; the only host sync is reading the token ids back.  When the step that must
+        follow is already known (_next_step_is_certain) it is launched before this one's tokens are returned, and the
+        next call only checks that it asks for exactly that step."""
         bs = len(seqs)
         g = self.graph_vars
         host = self._host_stage_np
         padded = next(x for x in self.graph_bs if x >= bs)
         ntok = self._continues_previous_step(seqs, padded)
         cache = getattr(self, "_pack_cache", None)
-        if ntok is not None:                 # the device advances its own copy of the step: only the header travels
-            host[0], host[1] = bs, cache["key"][1] | kernels.STAGE_ADVANCE
+        continued = ntok is not None
+        if self._step_ahead and not continued:
+            self._wait_for_step()            # before the pinned buffer it reads is rewritten
+            self._drop_step_ahead()
+        if self._step_ahead:                 # the step asked for is the one already running
+            self._step_ahead = False
+            self._ahead_backoff = 0
         else:
-            n, cols = self._pack_decode(seqs, host[2:])
-            host[0], host[1] = bs, cols      # header read on the device by the graph's own staging node
-            cache = self._pack_cache
-            ntok = cache["ntok"].tolist()
-        g["padded_bs"] = padded
-        self._replay(padded)
+            if continued:                    # the device advances its own copy of the step: only the header travels
+                host[0], host[1] = bs, cache["key"][1] | kernels.STAGE_ADVANCE
+            else:
+                n, cols = self._pack_decode(seqs, host[2:])
+                host[0], host[1] = bs, cols  # header read on the device by the graph's own staging node
+                cache = self._pack_cache
+                ntok = cache["ntok"].tolist()
+            host[1] |= self._step_back
+            self._step_back = 0
+            g["padded_bs"] = padded
+            self._replay(padded)
         self._wait_for_step()
         tokens = self._host_tokens_np[:bs].tolist()
         cache["padded"], cache["tokens"], cache["next_ntok"] = padded, tokens, [x + 1 for x in ntok]
+        if self.run_ahead and self._next_step_is_certain(seqs, cache, ntok, tokens):
+            if self._ahead_hold == 0:
+                host[0], host[1] = bs, cache["key"][1] | kernels.STAGE_ADVANCE
+                self._replay(padded)
+                self._step_ahead = True
+            else:
+                self._ahead_hold -= 1
         return tokens
+
+    def _next_step_is_certain(self, seqs: list[Sequence], cache: dict, ntok: list[int], tokens: list[int]) -> bool:
+        """May the decode step after this one be launched before the caller has asked for it?  Only if the caller's
+        own rules leave it no other next step for these sequences: none of them ends on the token just sampled
+        (its completion stays short of max_tokens; the token is not the end-of-sequence id unless the sequence ignores
+        it: Scheduler.postprocess, nanovllm/engine/scheduler.py:65-71) and none needs a new block for the next token
+        (BlockManager.may_append allocates when len % block_size == 1, block_manager.py:96-99 - the only point at which
+        a running sequence can be preempted, scheduler.py:45-52).  The count of such steps ahead is taken once per
+        full packing and counted down.  A caller that still presents another step (new prompts arrived, sequences
+        aborted) is served correctly - the launched step is dropped (_drop_step_ahead) - but has waited for it.
+        The block rule is what correctness needs (a step launched without the block it would write to has no slot);
+        the two ending rules only spare a launch that is certain to be dropped: the row such a step writes for an
+        ended sequence lies in a freed block that carries no hash, and whoever gets the block writes before reading."""
+        sure = cache.get("sure")
+        if sure is None:
+            n = np.asarray(ntok, dtype=np.int64)
+            if "limit" not in cache:
+                cache["limit"] = np.array([s.num_prompt_tokens + s.max_tokens for s in seqs], dtype=np.int64)
+                cache["eos_ends"] = any(not s.ignore_eos for s in seqs)
+            # steps from here in which nobody enters a new block / nobody reaches max_tokens
+            sure = int(min(((-n) % self.block_size).min(), (cache["limit"] - n - 1).min()))
+        cache["sure"] = sure - 1
+        if sure < 1:
+            return False
+        if cache["eos_ends"]:
+            eos = self.config.eos
+            if eos in tokens and any(t == eos and not s.ignore_eos for s, t in zip(seqs, tokens)):
+                return False
+        return True
+
+    def _drop_step_ahead(self) -> None:
+        """The caller asked for something else than the step launched ahead of it.  That step's results are not used:
+        its tokens are never returned, the next decode step is packed on the host in full (ids, positions, slots,
+        context lengths, tables), and the K/V rows it wrote are the rows of the token every one of its sequences has
+        just been given - the step that does decode that token writes the same values there again (rows of a sequence
+        that ended cannot be among them: see _next_step_is_certain).  Its sampler draw is given back
+        (STAGE_STEP_BACK) so that later draws are those of a run that never launched it.  Work queued after it on the
+        stream runs after it; only the pinned staging buffer needs the host to wait, which the graph path does."""
+        if not self._step_ahead:
+            return
+        self._step_ahead = False
+        self._step_back = kernels.STAGE_STEP_BACK
+        # a caller that keeps asking for other steps than the certain one (it repeats a step, say) soon stops paying
+        # for launches it does not use: 1, 2, 4 ... 64 certain steps are let pass before the next is launched ahead
+        self._ahead_backoff = min(64, max(1, 2 * self._ahead_backoff))
+        self._ahead_hold = self._ahead_backoff
+        cache = getattr(self, "_pack_cache", None)
+        if cache is not None:
+            cache["tokens"] = None           # the device's copy of the step is one ahead: no continuing from it
 
     def _wait_for_step(self) -> None:
         """Block until the replayed graph (which ends by delivering the tokens to pinned host memory) has finished.
@@ -338,6 +409,7 @@ class ModelRunner:
             cached = self._pack_cache = {"seqs": list(seqs), "key": None, "tokens": None,
                                          "temps": np.array([seq.temperature for seq in seqs], dtype=np.float32)}
         cached["ntok"] = ntok_copy
+        cached["sure"] = None                # steps ahead known to be plain continuations: counted again from here
         host[4 * bs:5 * bs].view(np.float32)[:] = cached["temps"]
         tables = host[5 * bs:n].reshape(bs, cols)
         key = (total, cols, Sequence.table_epoch)
@@ -586,5 +658,10 @@ class ModelRunner:
 
     max_graph_bs = 0
     graph_has_head = False
+    run_ahead = False
+    _step_ahead = False
+    _step_back = 0
+    _ahead_backoff = 0
+    _ahead_hold = 0
     decode_result_policy = 0
     prefill_result_policy = 0

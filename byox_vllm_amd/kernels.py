@@ -348,6 +348,7 @@ def stage_decode_inputs(ids, positions, slots, context_lens, block_tables, g):
 
 
 STAGE_ADVANCE = 0x40000000   # header word 1 of the packed buffer: continue the previous step on the device
+STAGE_STEP_BACK = 0x20000000  # header word 1: the previous launch was discarded, take its step count back first
 
 
 def stage_decode_packed(packed, bs, bt_cols, g, prev_tokens=None, block_size=0):

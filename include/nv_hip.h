@@ -260,8 +260,12 @@ int nv_stage_decode_packed(const int32_t* packed, int bs, int padded_bs, int bt_
  * the device from the tables the previous full staging left there; block tables and temperatures stay.  Without the
  * flag the call is nv_stage_decode_packed's header form.  The host decides per step which form applies (same rows, each
  * one token longer by exactly the token returned, no block table changed) by setting the flag in the pinned buffer,
- * so one captured launch serves both. */
+ * so one captured launch serves both.
+ * NV_STAGE_STEP_BACK in header word 1 (either form): *step_counter is first reduced by 1.  A host that launched a step
+ * before its caller asked for it, and then had to throw that step away, sets it on the next launch so that the
+ * sampler's draws are those of a run in which the discarded step never happened. */
 #define NV_STAGE_ADVANCE 0x40000000
+#define NV_STAGE_STEP_BACK 0x20000000
 int nv_stage_decode_packed_advance(const int32_t* packed, int padded_bs, int64_t* g_ids, int64_t* g_positions,
                                    int32_t* g_slots, int32_t* g_context_lens, int32_t* g_block_tables, int g_bt_cols,
                                    float* g_temperatures, uint64_t* step_counter, const int64_t* prev_tokens,

@@ -411,3 +411,169 @@ def test_scheduler_quiet_steps_equal_the_full_pass():
         assert fast == slow, f"seed {seed}"
         total_hits += hits
     assert total_hits > 50          # the shortcut was actually taken
+
+
+def test_step_launched_ahead_changes_nothing_but_the_order_of_host_work():
+    """The runner launches the next decode step before the caller asks for it when no other next step is possible
+    (_next_step_is_certain).  Host logic only, against a device emulated in numpy (the staging kernel's two forms, a
+    KV cache indexed by slot, a step counter that feeds the "sampler"; a token is a hash of everything its sequence has
+    in the cache plus the counter, so a wrong slot, a stale table, a lost or doubled draw or a row overwritten by a
+    dropped step changes the tokens).  The real Scheduler drives it over random workloads with arrivals in mid-run,
+    EOS, max_tokens, preemption and prefix-cache hits: tokens, finish order and block tables must equal the run that
+    never launches ahead, steps must have been launched ahead, and some of them dropped."""
+    import itertools
+    import random
+    import numpy as np
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.sampling_params import SamplingParams
+
+    BLOCK, ROWS, COLS = 8, 8, 16
+
+    class Device:
+        def __init__(self, runner):
+            self.r, self.step, self.prefills = runner, 0, 0
+            self.ids, self.pos = np.zeros(ROWS, np.int64), np.zeros(ROWS, np.int64)
+            self.slots, self.ctx = np.full(ROWS, -1, np.int64), np.zeros(ROWS, np.int64)
+            self.tables, self.tokens = np.full((ROWS, COLS), -1, np.int64), np.zeros(ROWS, np.int64)
+            self.kv, self.launched = {}, 0
+
+        def digest(self, table, n, salt):
+            h = salt * 1000003
+            for pos in range(n):
+                tok, at = self.kv[table[pos // BLOCK] * BLOCK + pos % BLOCK]
+                assert at == pos
+                h = (h * 31 + tok * 7 + pos) % 2147483647
+            return [3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15][h % 12]
+
+        def replay(self, padded):
+            host = self.r._host_stage_np
+            bs, word = int(host[0]), int(host[1])
+            self.launched += 1
+            if word & kernels.STAGE_STEP_BACK:
+                word &= ~kernels.STAGE_STEP_BACK
+                self.step -= 1
+            if word & kernels.STAGE_ADVANCE:
+                cols = word & ~kernels.STAGE_ADVANCE
+                for i in range(bs):
+                    self.ids[i], self.pos[i], self.ctx[i] = self.tokens[i], self.pos[i] + 1, self.ctx[i] + 1
+                    col = int(self.pos[i]) // BLOCK
+                    blk = self.tables[i, col] if col < cols else -1
+                    self.slots[i] = blk * BLOCK + self.pos[i] % BLOCK if blk >= 0 else -1
+            else:
+                p = host[2:]
+                self.ids[:bs], self.pos[:bs] = p[:bs], p[bs:2 * bs]
+                self.slots[:bs], self.ctx[:bs] = p[2 * bs:3 * bs], p[3 * bs:4 * bs]
+                self.tables[:bs, :word] = p[5 * bs:5 * bs + bs * word].reshape(bs, word)
+            self.step += 1
+            for i in range(bs):
+                assert self.slots[i] >= 0
+                self.kv[int(self.slots[i])] = (int(self.ids[i]), int(self.pos[i]))
+                self.tokens[i] = self.digest(self.tables[i], int(self.ctx[i]), self.step)
+            self.r._host_tokens_np[:bs] = self.tokens[:bs]
+
+        def prefill(self, seqs):
+            self.prefills += 1
+            out = []
+            for s in seqs:
+                for pos in range(s.num_cached_tokens, len(s)):
+                    self.kv[s.block_table[pos // BLOCK] * BLOCK + pos % BLOCK] = (s[pos], pos)
+                out.append(self.digest(s.block_table, len(s), -self.prefills))
+            return SimpleNamespace(tolist=lambda: out)
+
+    def emulated(ahead, cfg):
+        runner = ModelRunner.__new__(ModelRunner)
+        runner.block_size, runner.device, runner.config, runner.rank = BLOCK, torch.device("cpu"), cfg, 0
+        runner.device_bookkeeping, runner.run_ahead, runner.enforce_eager, runner.world_size = True, ahead, False, 1
+        runner.graph_bs, runner.max_graph_bs, runner.graph_has_head, runner.graph_vars = [2, 4, ROWS], ROWS, True, {}
+        runner._host_stage_np = np.zeros(2 + ROWS * (5 + COLS), np.int32)
+        runner._host_tokens_np = np.zeros(ROWS, np.int64)
+        dev = Device(runner)
+        runner._replay, runner._wait_for_step = dev.replay, lambda: None
+        runner._prepare_prefill, runner._prepare_sample = (lambda seqs: (seqs, None)), (lambda seqs: None)
+        runner._run_model = lambda seqs, positions, is_prefill: dev.prefill(seqs)
+        runner.sampler = lambda logits, temperatures: logits
+        dropped = [0]
+        real_drop = runner._drop_step_ahead
+
+        def counting_drop():
+            dropped[0] += runner._step_ahead
+            real_drop()
+        runner._drop_step_ahead = counting_drop
+        return runner, dev, dropped
+
+    def drive(ahead, seed):
+        rng = random.Random(seed)
+        Sequence.counter = itertools.count()
+        cfg = SimpleNamespace(max_num_seqs=6, max_num_batched_tokens=200, eos=3, num_kvcache_blocks=rng.choice([14, 18, 48]),
+                              kvcache_block_size=BLOCK, scheduler_quiet_steps=True)
+        sch = Scheduler(cfg)
+        runner, dev, dropped = emulated(ahead, cfg)
+        shared = [rng.randrange(4, 50) for _ in range(2 * BLOCK)]
+        pending = []
+        for i in range(10):
+            prompt = (shared if rng.random() < 0.4 else []) + [rng.randrange(4, 50) for _ in range(rng.randrange(1, 30))]
+            sp = SamplingParams(temperature=1.0, max_tokens=rng.randrange(1, 60), ignore_eos=rng.random() < 0.5)
+            pending.append((rng.randrange(0, 60), Sequence(prompt, BLOCK, sp)))
+        trace, step = [], 0
+        while (pending or not sch.is_finished()) and step < 3000:
+            for item in [p for p in pending if p[0] <= step]:
+                sch.add(item[1])
+                pending.remove(item)
+            step += 1
+            if sch.is_finished():
+                continue
+            seqs, is_prefill = sch.schedule()
+            if not seqs:
+                continue
+            toks = runner.run(seqs, is_prefill)
+            trace.append((is_prefill, [s.seq_id for s in seqs], list(toks), [list(s.block_table) for s in seqs]))
+            trace.append([s.seq_id for s in sch.postprocess(seqs, toks)])
+        assert step < 3000
+        decode_steps = sum(1 for t in trace[::2] if not t[0])
+        return trace, dev.launched - decode_steps, dropped[0]
+
+    extra_total = dropped_total = 0
+    for seed in range(25):
+        plain, extra0, dropped0 = drive(False, seed)
+        ahead, extra, dropped = drive(True, seed)
+        assert extra0 == 0 and dropped0 == 0
+        assert ahead == plain, f"seed {seed}"
+        assert extra == dropped or extra == dropped + 1, (extra, dropped)   # every unused launch was dropped (the last may be in flight)
+        extra_total += extra
+        dropped_total += dropped
+    assert dropped_total > 5, dropped_total
+
+    # a caller that repeats one step over and over (a timing loop) never asks for the step launched ahead: after a few
+    # drops it is no longer launched (1, 2, 4 ... 64 certain steps pass before the next attempt), and the tokens (which
+    # move with the step counter) are those of the runner that never launches ahead
+    runs = []
+    for ahead in (True, False):
+        runner, dev, dropped = emulated(ahead, SimpleNamespace(eos=-1))
+        seqs = [Sequence(list(range(20, 20 + n)), BLOCK, SamplingParams(temperature=1.0, max_tokens=1000, ignore_eos=True))
+                for n in (3, 10)]
+        seqs[0].block_table, seqs[1].block_table = [0], [1, 2]
+        runner.run(seqs, True)
+        runs.append(([runner.run(seqs, False) for _ in range(201)], dropped[0], dev.launched))
+    assert runs[0][0] == runs[1][0] and runs[1][1:] == (0, 201)
+    assert 3 <= runs[0][1] <= 9 and runs[0][2] == 201 + runs[0][1], runs[0][1:]
+
+
+def test_next_step_is_certain_counts_down_to_boundaries_and_limits():
+    import numpy as np
+    from byox_vllm_amd.sampling_params import SamplingParams
+    runner = ModelRunner.__new__(ModelRunner)
+    runner.block_size, runner.config = 8, SimpleNamespace(eos=3)
+    seqs = [Sequence(list(range(10, 10 + n)), 8, SamplingParams(temperature=1.0, max_tokens=m, ignore_eos=ig))
+            for n, m, ig in ((5, 100, True), (3, 4, False))]
+    cache = {"sure": None}
+    # lengths 5 and 3: the first enters a new block when it holds 9 tokens, i.e. the step with 8 tokens is the last
+    # certain one to launch from (sure: 3, then 2, 1, 0); the second ends with its 4th completion token (3 + 4 = 7)
+    assert runner._next_step_is_certain(seqs, cache, [5, 3], [7, 7]) and cache["sure"] == 2
+    assert runner._next_step_is_certain(seqs, cache, [6, 4], [3, 7])          # EOS for a sequence that ignores it
+    assert not runner._next_step_is_certain(seqs, cache, [7, 5], [7, 3])      # EOS that ends the second sequence
+    assert cache["sure"] == 0
+    assert not runner._next_step_is_certain(seqs, cache, [8, 6], [7, 7])      # the first is at its block's end
+    cache = {"sure": None}
+    assert not runner._next_step_is_certain(seqs, cache, [6, 6], [7, 7])      # the second reaches max_tokens with this token
+    cache = {"sure": None}
+    assert runner._next_step_is_certain(seqs, cache, [6, 5], [7, 7]) and cache["sure"] == 0

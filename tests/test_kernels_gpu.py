@@ -1073,6 +1073,20 @@ def test_stage_decode_advance_continues_the_previous_step_on_the_device():
     assert g["slot_mapping"].cpu().tolist() == [3 * 16 + 5, 5 * 16 + 15, 8 * 16 + 0, -1, -1, -1, -1, -1]
     assert torch.equal(g["block_tables"].cpu(), before_tables) and g["temperatures"].cpu().tolist()[:4] == temps.tolist()
     assert g["step"].item() == 2
+    # NV_STAGE_STEP_BACK: the step counter first gives back the previous launch's count, in either form; the flag is
+    # not taken for part of the table width
+    header_only[1] |= kernels.STAGE_STEP_BACK
+    buf.copy_(torch.from_numpy(header_only))
+    kernels.stage_decode_packed(buf, -1, 0, g, prev_tokens=prev, block_size=block)
+    assert g["step"].item() == 2 and g["positions"].cpu().tolist()[:4] == [n + 1 for n in lens]
+    assert g["slot_mapping"].cpu().tolist()[:4] == [3 * 16 + 6, -1, 8 * 16 + 1, -1]
+    full_again = payload.copy()
+    full_again[1] |= kernels.STAGE_STEP_BACK
+    buf.copy_(torch.from_numpy(full_again))
+    kernels.stage_decode_packed(buf, -1, 0, g, prev_tokens=prev, block_size=block)
+    assert g["step"].item() == 2 and g["input_ids"].cpu().tolist()[:4] == [11, 12, 13, 14]
+    assert g["positions"].cpu().tolist()[:4] == [n - 1 for n in lens]
+    assert torch.equal(g["block_tables"].cpu(), before_tables)
 
 
 def test_bad_arguments_are_rejected_not_launched():

@@ -509,3 +509,71 @@ def test_device_side_bookkeeping_equals_host_packing(golden, monkeypatch):
         runner.exit()
     assert outs[0] == outs[1]
     assert advanced[1] == 0 and advanced[0] >= BS, advanced   # most steps cross no block boundary
+
+
+def test_steps_launched_ahead_return_the_tokens_of_steps_launched_on_demand(golden, monkeypatch):
+    """With NV_RUN_AHEAD (the default) the runner launches a decode step before the caller asks for it whenever no other
+    next step is possible.  Sampled tokens (temperature 0.8: the draws depend on the device's step counter), over
+    block boundaries, a sequence that reaches max_tokens, a prompt that arrives in mid-run (the step launched ahead is
+    dropped by the prefill) and a sequence taken out by the caller without warning (dropped by the next decode
+    call): identical to the run that launches every step on demand, and steps were launched ahead and dropped."""
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    from byox_vllm_amd.engine.block_manager import BlockManager
+    from byox_vllm_amd.engine.sequence import Sequence
+    from byox_vllm_amd.sampling_params import SamplingParams
+    outs, stats, when = [], [], {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NV_RUN_AHEAD", mode)
+        runner = make_runner(cfg, weights, enforce_eager=False, max_num_seqs=8, num_blocks=48)
+        assert runner.run_ahead == (mode == "1")
+        launches, dropped = [0], [0]
+
+        def counted_replay(padded, real=runner._replay, launches=launches):
+            launches[0] += 1
+            real(padded)
+
+        def counted_drop(real=runner._drop_step_ahead, runner=runner, dropped=dropped):
+            dropped[0] += runner._step_ahead
+            real()
+        runner._replay, runner._drop_step_ahead = counted_replay, counted_drop
+        bm = BlockManager(48, BS)
+        rng = np.random.RandomState(21)
+        seqs = [Sequence(rng.randint(0, 256, size=n).tolist(), BS, SamplingParams(temperature=0.8, max_tokens=m))
+                for n, m in ((5, 200), (BS - 3, 200), (2 * BS - 1, BS + 2), (33, 200))]
+        late = Sequence(rng.randint(0, 256, size=11).tolist(), BS, SamplingParams(temperature=0.8, max_tokens=200))
+        for s in seqs:
+            bm.allocate(s)
+        toks = [runner.run(seqs, True)]
+        decode_calls = 0
+        for step in range(3 * BS):
+            for s, tkn in zip(seqs, toks[-1]):
+                s.append_token(tkn)
+            done = [s for s in seqs if s.num_completion_tokens == s.max_tokens]
+            for s in done:                                   # what Scheduler.postprocess does at max_tokens
+                bm.deallocate(s)
+                seqs.remove(s)
+            # both events at a step that has a step launched ahead in flight (found in the first run, repeated in the second)
+            if mode == "1" and "arrive" not in when and step >= BS + 5 and runner._step_ahead:
+                when["arrive"] = step
+            elif mode == "1" and "remove" not in when and step >= 2 * BS + 3 and runner._step_ahead:
+                when["remove"] = step
+            if step == when.get("arrive"):                   # a prompt arrives: its prefill comes before the next decode
+                bm.allocate(late)
+                toks.append(runner.run([late], True))
+                late.append_token(toks[-1][0])
+                seqs.append(late)
+            if step == when.get("remove"):                   # the caller drops a sequence the runner could not know about
+                bm.deallocate(seqs.pop(0))
+            for s in seqs:
+                bm.may_append(s)
+            toks.append(runner.run(seqs, False))
+            decode_calls += 1
+        outs.append(toks)
+        stats.append((launches[0] - decode_calls, dropped[0]))
+        runner.exit()
+    assert outs[0] == outs[1]
+    assert stats[1] == (0, 0) and set(when) == {"arrive", "remove"}, (stats, when)
+    extra, dropped = stats[0]
+    assert dropped >= 2 and extra in (dropped, dropped + 1), stats     # the prefill and the removal each dropped one
+    print(f"steps launched ahead and dropped: {dropped}, decode launches beyond the calls: {extra}")
