@@ -1,4 +1,5 @@
-# Repeated A/B of environment settings on one workload: bash scripts/r03_env_rep.sh OUT REPEATS STEPS WORKLOAD "VAR=a" "VAR=b" ...
+# Repeated A/B of environment settings on one workload: [FIELD=value] bash scripts/r03_env_rep.sh OUT REPEATS STEPS WORKLOAD "VAR=a" "VAR=b" ...
+# (FIELD: the JSON field compared, ms_per_step unless given)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03/$1; shift; N=$1; shift; S=$1; shift; W=$1; shift; mkdir -p $R/gpurun_out/r03; rm -f $O
 cd $R
@@ -8,7 +9,7 @@ for rep in $(seq $N); do
 import sys, json
 for ln in sys.stdin:
     if ln.startswith('{'):
-        d = json.loads(ln); print('$setting', d['ms_per_step'])
+        d = json.loads(ln); print('$setting', d['${FIELD:-ms_per_step}'])
 " >> $O || exit 1
   done
 done
