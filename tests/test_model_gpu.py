@@ -577,3 +577,59 @@ def test_steps_launched_ahead_return_the_tokens_of_steps_launched_on_demand(gold
     extra, dropped = stats[0]
     assert dropped >= 2 and extra in (dropped, dropped + 1), stats     # the prefill and the removal each dropped one
     print(f"steps launched ahead and dropped: {dropped}, decode launches beyond the calls: {extra}")
+
+
+def test_generate_with_steps_launched_ahead_equals_generate_on_demand(golden, monkeypatch):
+    """The whole engine (Scheduler + BlockManager + runner, captured decode graphs) with sampled tokens, sequences that
+    end on EOS or at different max_tokens, too few KV blocks for the batch (preemption and re-prefill) and prompts
+    that arrive while others decode: NV_RUN_AHEAD on (default) and off produce the same token ids for every request,
+    and steps were in fact launched ahead, some of them dropped."""
+    from byox_vllm_amd import LLM, SamplingParams
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    rng = np.random.RandomState(33)
+    prompts = [rng.randint(0, 256, size=n).tolist() for n in (9, 30, 17, 28, 5, 12)]
+    limits = [40, 25, 60, 33, 48, 20]
+    arrive = [0, 0, 0, 6, 19, 30]                      # engine step at which each request is added
+
+    def run(mode, eos):
+        monkeypatch.setenv("NV_RUN_AHEAD", mode)
+        get_rope.cache_clear()
+        llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=14,
+                  enforce_eager=False, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8)
+        runner = llm.model_runner
+        launched, dropped = [0], [0]
+
+        def counted_replay(padded, real=runner._replay):
+            launched[0] += 1
+            real(padded)
+
+        def counted_drop(real=runner._drop_step_ahead):
+            dropped[0] += runner._step_ahead
+            real()
+        runner._replay, runner._drop_step_ahead = counted_replay, counted_drop
+        llm.config.eos = llm.scheduler.eos = eos
+        results, step, todo = {}, 0, list(range(len(prompts)))
+        try:
+            while todo or not llm._is_finished():
+                for i in [i for i in todo if arrive[i] <= step]:
+                    llm._add_request(prompts[i], SamplingParams(temperature=0.8, max_tokens=limits[i], ignore_eos=i % 2 == 1))
+                    todo.remove(i)
+                finished, _ = llm._step()
+                results.update(dict(finished))
+                step += 1
+                assert step < 2000
+        finally:
+            llm._exit()
+        return [results[k] for k in sorted(results)], launched[0], dropped[0]
+
+    free_running, _, _ = run("0", -1)
+    # an EOS id that ends at least one EOS-honouring request in mid-run
+    eos = next(t for i in (0, 2, 4) for t in free_running[i][5:15])
+    on_demand, n0, d0 = run("0", eos)
+    ahead, n1, d1 = run("1", eos)
+    assert d0 == 0 and ahead == on_demand
+    assert any(len(on_demand[i]) < limits[i] for i in (0, 2, 4))          # the EOS did end somebody early
+    assert d1 >= 1 and n1 == n0 + d1, (n0, n1, d0, d1)                    # every extra launch is a dropped step
+    print(f"graph launches on demand {n0}, with steps ahead {n1} ({d1} dropped)")
