@@ -29,6 +29,7 @@ def test_default_line_is_the_metric_configuration_with_roofline_and_cpu_baseline
     cfg = d["config"]
     assert cfg["workload"] == "qwen2-0.5b-w4a16-b128-s1024" and cfg["weight_format"] == "w4a16"
     assert cfg["batch_per_replica"] == 128 and cfg["context"] == 1024 and cfg["graph"] is True and "model" not in cfg
+    assert cfg["run_ahead"] is True          # the line says that steps were launched ahead of the driver's calls
     # value = whole-job tokens per second of the timed steps
     assert abs(d["value"] - 128 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
     assert 0.5 < d["ms_per_step"] < 5.0
