@@ -579,25 +579,39 @@ def test_steps_launched_ahead_return_the_tokens_of_steps_launched_on_demand(gold
     print(f"steps launched ahead and dropped: {dropped}, decode launches beyond the calls: {extra}")
 
 
-def test_generate_with_steps_launched_ahead_equals_generate_on_demand(golden, monkeypatch):
+@pytest.mark.parametrize("case", ["six requests", "random 80", "random 120"])
+def test_generate_with_steps_launched_ahead_equals_generate_on_demand(golden, monkeypatch, case):
     """The whole engine (Scheduler + BlockManager + runner, captured decode graphs) with sampled tokens, sequences that
     end on EOS or at different max_tokens, too few KV blocks for the batch (preemption and re-prefill) and prompts
     that arrive while others decode: NV_RUN_AHEAD on (default) and off produce the same token ids for every request,
-    and steps were in fact launched ahead, some of them dropped."""
+    and steps were in fact launched ahead, some of them dropped.  The random cases draw 80 / 120 requests (prompts of
+    1-60 tokens, some sharing a prefix of two blocks, 1-60 new tokens, arrival steps spread over the run) for up to 16
+    sequences at a time on a block pool that cannot hold them all."""
     from byox_vllm_amd import LLM, SamplingParams
     from byox_vllm_amd.layers.rotary_embedding import get_rope
     _, _, weights = _golden_weights(golden, "qwen2")
     cfg = OM.tiny_config("qwen2", torch.bfloat16)
-    rng = np.random.RandomState(33)
-    prompts = [rng.randint(0, 256, size=n).tolist() for n in (9, 30, 17, 28, 5, 12)]
-    limits = [40, 25, 60, 33, 48, 20]
-    arrive = [0, 0, 0, 6, 19, 30]                      # engine step at which each request is added
+    if case == "six requests":
+        rng = np.random.RandomState(33)
+        prompts = [rng.randint(0, 256, size=n).tolist() for n in (9, 30, 17, 28, 5, 12)]
+        limits = [40, 25, 60, 33, 48, 20]
+        arrive = [0, 0, 0, 6, 19, 30]                      # engine step at which each request is added
+        blocks, max_seqs = 14, 8
+    else:
+        n = int(case.split()[1])
+        rng = np.random.RandomState(n)
+        shared = rng.randint(0, 256, size=2 * BS).tolist()
+        prompts = [(shared if rng.rand() < 0.3 else []) + rng.randint(0, 256, size=rng.randint(1, 61 - 2 * BS)).tolist()
+                   for _ in range(n)]
+        limits = [int(rng.randint(1, 61)) for _ in range(n)]
+        arrive = sorted(int(rng.randint(0, 4 * n)) for _ in range(n))
+        blocks, max_seqs = 40, 16
 
     def run(mode, eos):
         monkeypatch.setenv("NV_RUN_AHEAD", mode)
         get_rope.cache_clear()
-        llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=14,
-                  enforce_eager=False, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=8)
+        llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=blocks,
+                  enforce_eager=False, max_model_len=128, max_num_batched_tokens=256, max_num_seqs=max_seqs)
         runner = llm.model_runner
         launched, dropped = [0], [0]
 
@@ -610,26 +624,29 @@ def test_generate_with_steps_launched_ahead_equals_generate_on_demand(golden, mo
             real()
         runner._replay, runner._drop_step_ahead = counted_replay, counted_drop
         llm.config.eos = llm.scheduler.eos = eos
-        results, step, todo = {}, 0, list(range(len(prompts)))
+        results, order, step, todo = {}, [], 0, list(range(len(prompts)))
         try:
             while todo or not llm._is_finished():
                 for i in [i for i in todo if arrive[i] <= step]:
                     llm._add_request(prompts[i], SamplingParams(temperature=0.8, max_tokens=limits[i], ignore_eos=i % 2 == 1))
                     todo.remove(i)
-                finished, _ = llm._step()
-                results.update(dict(finished))
+                if not llm._is_finished():
+                    finished, _ = llm._step()
+                    results.update(dict(finished))
+                    order += [k for k, _ in finished]
                 step += 1
-                assert step < 2000
+                assert step < 20000
         finally:
             llm._exit()
-        return [results[k] for k in sorted(results)], launched[0], dropped[0]
+        first = min(results)
+        return [results[k] for k in sorted(results)], [k - first for k in order], launched[0], dropped[0]
 
-    free_running, _, _ = run("0", -1)
+    free_running, _, _, _ = run("0", -1)
     # an EOS id that ends at least one EOS-honouring request in mid-run
-    eos = next(t for i in (0, 2, 4) for t in free_running[i][5:15])
-    on_demand, n0, d0 = run("0", eos)
-    ahead, n1, d1 = run("1", eos)
-    assert d0 == 0 and ahead == on_demand
-    assert any(len(on_demand[i]) < limits[i] for i in (0, 2, 4))          # the EOS did end somebody early
+    eos = next(t for i in range(0, len(prompts), 2) for t in free_running[i][5:15])
+    on_demand, order0, n0, d0 = run("0", eos)
+    ahead, order1, n1, d1 = run("1", eos)
+    assert d0 == 0 and ahead == on_demand and order1 == order0
+    assert any(len(on_demand[i]) < limits[i] for i in range(0, len(prompts), 2))     # the EOS did end somebody early
     assert d1 >= 1 and n1 == n0 + d1, (n0, n1, d0, d1)                    # every extra launch is a dropped step
-    print(f"graph launches on demand {n0}, with steps ahead {n1} ({d1} dropped)")
+    print(f"{case}: graph launches on demand {n0}, with steps ahead {n1} ({d1} dropped)")
