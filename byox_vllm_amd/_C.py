@@ -38,6 +38,9 @@ _PROTOS = {
     "nv_paged_attn_decode_static": (_i, [_p, _i64, _p, _p, _p, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "nv_attn_prefill": (_i, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "nv_silu_mul": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "nv_gemm_lt_available": (_i, []),
+    "nv_gemm_lt": (_i, [_p, _i64, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _sz, _p]),
+    "nv_weight_expand": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "nv_gemm_workspace_bytes": (_sz, [_i64, _i, _i]),
     "nv_gemm_pick_split_k": (_i, [_i64, _i, _i, _i]),
     "nv_gemm": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _i, _p, _sz, _i, _i, _p]),

@@ -252,6 +252,58 @@ def pick_split_k(M, N, K, wfmt=_C.W_INT4):
     return lib().nv_gemm_pick_split_k(M, N, K, wfmt)
 
 
+# Rows from which a product goes through the vendor library (nv_gemm_lt) instead of nv_gemm's decode-shaped tiles:
+# prefill steps.  Measured on the layer shapes of Qwen3-0.6B, Qwen2-0.5B and Qwen2-7B, weight expansion included
+# (scripts/r03_dense_prefill_gemm.py): at 1024 rows nv_gemm wins everywhere, at 2048 the two trade places by shape,
+# from 4096 on the library wins or ties (1.3-1.7 times faster from 8192).  NV_GEMM_LT_ROWS=0 switches the path off.
+MANY_ROWS = int(os.environ.get("NV_GEMM_LT_ROWS", "4096"))
+LT_WORKSPACE_BYTES = 128 << 20
+
+
+def expand_weight(w, gate_up_rows=False, out=None):
+    """Row-major [N, K] copy, in the model dtype, of a LinearWeight in any format (nv_weight_expand)."""
+    _require_device_weight(w, "expand_weight")
+    N, K = w.out_features, w.in_features
+    out = torch.empty(N, K, dtype=w.dtype, device=w.data.device) if out is None else out
+    assert out.is_contiguous() and out.shape == (N, K) and out.dtype == w.dtype
+    check(lib().nv_weight_expand(ptr(w.data), ptr(w.scales), w.fmt, N, K, int(gate_up_rows), dtype_code(w.dtype), ptr(out),
+                                 stream()), "nv_weight_expand")
+    return out
+
+
+def gemm_many_rows(x, w, bias=None, out=None, silu_mul=False):
+    """gemm() for prefill-sized x: the weight written out row-major into scratch, one vendor-library product, and for
+    gate/up weights the SiluAndMul pass over its result (same roundings as the fused epilogue: the product rounded to
+    the model dtype, silu rounded, the product with up rounded)."""
+    M, K = x.shape
+    N = w.out_features
+    dev = x.device
+    if w.fmt == _C.W_DENSE and not silu_mul:
+        wr = w.data
+    else:
+        wr = workspace(N * K * x.element_size(), dev, "gemm_lt_weight")[:N * K * x.element_size()].view(x.dtype).view(N, K)
+        expand_weight(w, gate_up_rows=silu_mul, out=wr)
+    if silu_mul:
+        y = workspace(M * N * x.element_size(), dev, "gemm_lt_gate_up")[:M * N * x.element_size()].view(x.dtype).view(M, N)
+    else:
+        y = torch.empty(M, N, dtype=x.dtype, device=dev) if out is None else out
+        assert y.stride(1) == 1 and y.shape == (M, N)
+    ws = workspace(LT_WORKSPACE_BYTES, dev, "gemm_lt")
+    check(lib().nv_gemm_lt(ptr(x), x.stride(0), ptr(wr), ptr(bias), ptr(y), y.stride(0), M, N, K, dtype_code(x.dtype),
+                           ptr(ws), LT_WORKSPACE_BYTES, stream()), "nv_gemm_lt")
+    if not silu_mul:
+        return y
+    out = torch.empty(M, N // 2, dtype=x.dtype, device=dev) if out is None else out
+    assert out.is_contiguous() and out.shape == (M, N // 2)
+    check(lib().nv_silu_mul(ptr(y), ptr(out), M, N // 2, dtype_code(x.dtype), stream()), "nv_silu_mul")
+    return out
+
+
+def use_many_rows_path(M, K, N) -> bool:
+    return bool(MANY_ROWS) and M >= MANY_ROWS and K % 128 == 0 and N % 16 == 0 and lib().nv_gemm_lt_available() == 1 \
+        and not torch.cuda.is_current_stream_capturing()
+
+
 def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=False):
     """x [M, K] @ w^T where ``w`` is a layers.quant.LinearWeight (dense, int8 or int4).
 
@@ -265,6 +317,8 @@ def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=Fa
     if bias is not None:
         assert bias.numel() == N and bias.dtype == x.dtype
     if split_k is None:
+        if use_many_rows_path(M, K, N) and (out is None or out.is_contiguous() or not silu_mul):
+            return gemm_many_rows(x, w, bias, out, silu_mul)
         split_k = 1 if silu_mul else pick_split_k(M, N, K, w.fmt)
     split_k = max(1, min(split_k, K // 128))
     if split_k == 1:

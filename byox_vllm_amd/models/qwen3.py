@@ -73,8 +73,9 @@ class Qwen3Attention(nn.Module):
         # Decode rows run inside a captured graph, where the library's estimate of GPU time decides.  A prefill step
         # is launched eagerly and is bound by the host up to about 2 k tokens (5.4 ms for 24 layers whatever the
         # size): there one launch less per layer wins (0.5B: 5.85 -> 5.49 ms at 2 k tokens; equal at 4 k).
+        many_rows = kernels.use_many_rows_path(rows, proj.packed.in_features, proj.packed.out_features)
         fused = self.fuse_qkv_rope and (
-            self.force_fuse_qkv_rope or (context.is_prefill and 16 <= rows <= 4096) or
+            self.force_fuse_qkv_rope or (context.is_prefill and 16 <= rows <= 4096 and not many_rows) or
             kernels.lib().nv_gemm_rope_kv_store_is_faster(rows, proj.packed.in_features, proj.packed.fmt,
                                                           self.num_heads, self.num_kv_heads, self.head_dim))
         if fused:

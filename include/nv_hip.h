@@ -151,6 +151,25 @@ int nv_attn_prefill(const void* q, int64_t q_row_stride, const void* k, const vo
                     int num_seqs, int max_seqlen_q, int H, int Hkv, int D, int block_size, float scale,
                     int dtype, nv_stream_t stream);
 
+/* Many-row products (prefill) through the vendor library, for the same F.linear (nanovllm/layers/linear.py:49,70,144):
+ * out[M, N] = x[M, K] * W^T (+ bias), fp32 accumulation, one rounding.  W is ROW-MAJOR [N, K] in the model dtype — a
+ * weight kept in one of nv_gemm's formats is written out that way by nv_weight_expand first.  hipBLASLt is loaded on
+ * first use (dlopen); nv_gemm_lt_available() says whether that worked, and nv_gemm_lt fails with NV_ERR_INVALID if
+ * not.  workspace: device memory the library may use (workspace_bytes of it; the library asks for up to 64 MiB), nothing is allocated
+ * here.  Not for captured graphs (the library picks an algorithm per shape on the host at the first call). */
+int nv_gemm_lt_available(void);
+int nv_gemm_lt(const void* x, int64_t x_row_stride, const void* w_rowmajor, const void* bias, void* out,
+               int64_t out_row_stride, int M, int N, int K, int dtype, void* workspace, size_t workspace_bytes,
+               nv_stream_t stream);
+
+/* Weight of any nv_gemm format (NV_W_*) -> row-major [N, K] in the model dtype: tiled layouts un-tiled, int4 / int8
+ * dequantised as (u - 8) * s resp. q * s in fp32, rounded once (the oracle's dequantisation, so nv_gemm_lt on the result
+ * is "dequantise, then F.linear").  gate_up_rows != 0: the rows are stored in the order of nv_gemm's silu(gate)*up
+ * epilogue (gate 2i, gate 2i+1, up 2i, up 2i+1) and are written as [all gate rows; all up rows], the order
+ * nv_silu_mul reads.  No counterpart in the reference (its weights are row-major already). */
+int nv_weight_expand(const void* data, const void* scales, int fmt, int N, int K, int gate_up_rows, int dtype, void* out,
+                     nv_stream_t stream);
+
 /* SiluAndMul.forward — nanovllm/layers/activation.py:10-13.
  * out[t, i] = to_dtype(silu(x[t, i])) * x[t, I + i], x [T, 2I]. */
 int nv_silu_mul(const void* x, void* out, int64_t T, int I, int dtype, nv_stream_t stream);

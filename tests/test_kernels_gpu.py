@@ -705,9 +705,73 @@ def test_gemm_qwen2_7b_gate_up_silu(fmt, M, wide, monkeypatch):
     assert (err > unit).float().mean().item() < 2e-3
 
 
-@pytest.mark.parametrize("M", [640, 2100])
-def test_gemm_many_rows_silu_mul(M):
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("fmt", ["dense", "tiled", "w8a16", "w4a16"])
+@pytest.mark.parametrize("gate_up", [False, True])
+def test_weight_expand_is_the_oracles_dequantisation(name, fmt, gate_up):
+    """nv_weight_expand: any nv_gemm weight format back to row-major in the model dtype, bit for bit the weight the
+    oracle multiplies by (dense: the weight itself; int4 / int8: oracle/quant.py's dequantisation); rows stored for
+    the silu(gate)*up epilogue come back as [gate rows; up rows]."""
     from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import interleave_gate_up
+    dt = DT[name]
+    g = torch.Generator().manual_seed(5)
+    N, K = 352, 384
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    stored = interleave_gate_up(w) if gate_up else w
+    lw, _ = _weights_for(fmt, stored)
+    want = w if fmt in ("dense", "tiled") else (Q.dequantize_w4(*Q.quantize_w4(w)) if fmt == "w4a16" else
+                                                 Q.dequantize_w8(*Q.quantize_w8(w)))
+    got = kernels.expand_weight(lw, gate_up_rows=gate_up)
+    assert got.dtype == dt and torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("name", list(DT))
+@pytest.mark.parametrize("M,N,K", [(2048, 128, 128), (2500, 1152, 896), (4100, 896, 4864)])
+@pytest.mark.parametrize("fmt", ["dense", "tiled", "w8a16", "w4a16"])
+def test_gemm_many_rows_through_the_vendor_library(name, M, N, K, fmt, monkeypatch):
+    """From kernels.MANY_ROWS rows on, gemm() writes the weight out row-major and multiplies through nv_gemm_lt
+    (hipBLASLt): same contract as nv_gemm (F.linear on the dequantised weight, fp32 accumulation, one rounding; with
+    and without bias, into a strided output), and within one rounding of what nv_gemm itself returns."""
+    from byox_vllm_amd import kernels
+    dt = DT[name]
+    assert kernels.lib().nv_gemm_lt_available() == 1 and kernels.MANY_ROWS == 4096
+    monkeypatch.setattr(kernels, "MANY_ROWS", 2048)
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt)
+    lw, w_ref = _weights_for(fmt, w)
+    calls = []
+    real = kernels.gemm_many_rows
+    monkeypatch.setattr(kernels, "gemm_many_rows", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    # One rounding of the exact product, plus what fp32 accumulation of K terms leaves behind where the products cancel
+    # (a random walk of K roundings at 2^-24 of partial sums of a few units: 3e-5 at K = 4864, visible only in fp16
+    # outputs close to zero; nv_gemm shows the same, scripts/r03_lt_accuracy.py).
+    floor = 8.0 * K ** 0.5 * 2.0 ** -24
+
+    def close(got, want, ulps):
+        got, want = got.double().cpu(), want.double().cpu()
+        bad = (got - want).abs() > ulps * EPS[name] * 2 * want.abs() + floor
+        assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} beyond {ulps} ulp; max abs {(got - want).abs().max()}"
+
+    got = kernels.gemm(dev(x), lw, dev(bias))
+    close(got, torch.nn.functional.linear(x.double(), w_ref.double(), bias.double()), 1.0)
+    wide = dev(torch.zeros(M, N + 64, dtype=dt))
+    got2 = kernels.gemm(dev(x), lw, out=wide[:, 8:8 + N])
+    close(got2, torch.nn.functional.linear(x.double(), w_ref.double()), 1.0)
+    assert wide[:, :8].eq(0).all() and wide[:, 8 + N:].eq(0).all() and len(calls) == 2
+    monkeypatch.setattr(kernels, "MANY_ROWS", 0)
+    own = kernels.gemm(dev(x), lw, dev(bias))
+    assert len(calls) == 2
+    close(got, own, 2.0)      # each within one rounding of the exact product
+
+
+@pytest.mark.parametrize("M", [640, 2100])
+@pytest.mark.parametrize("vendor", [True, False])
+def test_gemm_many_rows_silu_mul(M, vendor, monkeypatch):
+    from byox_vllm_amd import kernels
+    monkeypatch.setattr(kernels, "MANY_ROWS", 2048 if vendor else 0)
     from byox_vllm_amd.layers.quant import LinearWeight, interleave_gate_up
     g = torch.Generator().manual_seed(23)
     K, inter = 256, 1536

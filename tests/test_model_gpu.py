@@ -650,3 +650,39 @@ def test_generate_with_steps_launched_ahead_equals_generate_on_demand(golden, mo
     assert any(len(on_demand[i]) < limits[i] for i in range(0, len(prompts), 2))     # the EOS did end somebody early
     assert d1 >= 1 and n1 == n0 + d1, (n0, n1, d0, d1)                    # every extra launch is a dropped step
     print(f"{case}: graph launches on demand {n0}, with steps ahead {n1} ({d1} dropped)")
+
+
+@pytest.mark.parametrize("quant,bits", [(None, 0), ("w8a16", 8), ("w4a16", 4)])
+def test_prefill_of_many_rows_through_the_vendor_library_vs_oracle(golden, quant, bits, monkeypatch):
+    """A prefill step of 4 500 tokens: every linear of the step goes through kernels.gemm_many_rows (weight written out
+    row-major, hipBLASLt product, SiluAndMul pass for gate/up), the q/k/v projection as an unfused launch.  Last-token
+    logits against the oracle (dequantised dense weights), and against the same step with the path switched off."""
+    from byox_vllm_amd import kernels
+    g, key, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    lens = [900] * 5
+    blocks_each = -(-lens[0] // BS)
+    tables = [list(range(i * blocks_each, (i + 1) * blocks_each)) for i in range(len(lens))]
+    rng = np.random.RandomState(4)
+    ids = torch.from_numpy(rng.randint(0, 256, size=sum(lens)))
+    ctx, pos = OM.prefill_ctx(lens, tables, BS)
+    cfg.max_position_embeddings = 1024          # the fixture's weights do not depend on it; RoPE tables do
+    om = OM.OracleQwen(cfg, OM.fake_quantize(weights, bits) if bits else weights, BS, blocks_each * len(lens))
+    want = om.compute_logits(om.forward(ids, pos, ctx), ctx).float()
+    outs = []
+    for rows in (4096, 0):
+        monkeypatch.setattr(kernels, "MANY_ROWS", rows)
+        calls = []
+        real = kernels.gemm_many_rows
+        monkeypatch.setattr(kernels, "gemm_many_rows", lambda *a, real=real, calls=calls, **k: (calls.append(1), real(*a, **k))[1])
+        runner = make_runner(cfg, weights, quantization=quant, num_blocks=blocks_each * len(lens), max_model_len=1024)
+        calls.clear()
+        got = forward(runner, ids, pos, ctx)
+        runner.exit()
+        monkeypatch.setattr(kernels, "gemm_many_rows", real)
+        layers = cfg.num_hidden_layers
+        assert len(calls) == (4 * layers if rows else 0), (rows, len(calls))   # qkv, o, gate_up, down of every layer
+        assert (got - want).abs().max().item() < LOGIT_TOL
+        outs.append(got)
+    assert (outs[0] - outs[1]).abs().max().item() < LOGIT_TOL
+    assert torch.equal(outs[0].argmax(-1), outs[1].argmax(-1)) or (want.topk(2, -1).values.diff(dim=-1).abs().min() < LOGIT_TOL)
