@@ -50,6 +50,8 @@ class ModelRunner:
             and not self.use_xgmi)
         self.world_size = config.tensor_parallel_size
         self.device_bookkeeping = os.environ.get("NV_DEVICE_BOOKKEEPING", "1") != "0"
+        # tensor-parallel decode steps travel as the packed staging buffer (run_packed); 0: as seven arrays (run_step)
+        self.tp_packed_steps = os.environ.get("NV_TP_PACKED_STEPS", "1") != "0"
         # launch the next decode step before the caller asks for it, whenever no other next step is possible
         self.run_ahead = self.device_bookkeeping and os.environ.get("NV_RUN_AHEAD", "1") != "0"
         self.spin_wait = os.environ.get("NV_SPIN_WAIT", "1") != "0"
@@ -193,6 +195,15 @@ class ModelRunner:
     def call(self, method_name, *args):
         if method_name == "run" and self.world_size > 1:
             seqs, is_prefill = args
+            if not is_prefill and not self.enforce_eager and 0 < len(seqs) <= self.max_graph_bs and self.tp_packed_steps:
+                # a decode step for the captured graphs: the control message is the packed buffer the single-rank
+                # path stages from (one array, built with the same caches), not seven tensors
+                host = self._host_stage_np
+                n, cols = self._pack_decode(seqs, host[2:])
+                host[0], host[1] = len(seqs), cols
+                if self.rank == 0 and getattr(self, "shm", None) is not None:
+                    self._write_shm("run_packed", host[:2 + n])
+                return self.run_packed(None)
             step = self._prepare_step(seqs, is_prefill)
             if self.rank == 0 and getattr(self, "shm", None) is not None:
                 self._write_shm("run_step", step)
@@ -449,6 +460,33 @@ class ModelRunner:
         if self.rank == 0:
             token_ids = self.sampler(logits, dev(step["temperatures"])).tolist()
         reset_context()
+        self._check_comm()
+        return token_ids
+
+    @torch.inference_mode()
+    def run_packed(self, packed):
+        """One decode step of a tensor-parallel job from the packed control message (layout of _pack_decode behind the
+        two header words {rows, table width}): one host-to-device copy and one staging launch fill the captured
+        graph's inputs on every rank - the same integers run_step receives as seven arrays (reference:
+        model_runner.py:206-235 on every rank after read_shm) - then the graph, the LM-head shard, the gather and, on
+        rank 0, the sampler.  ``packed`` is None on the rank that packed the step into its own staging buffer."""
+        host = self._host_stage_np
+        if packed is not None:
+            host[:packed.size] = packed
+        bs, cols = int(host[0]), int(host[1])
+        words = 2 + bs * (5 + cols)
+        g = self.graph_vars
+        padded = next(x for x in self.graph_bs if x >= bs)
+        g["padded_bs"] = padded
+        self._dev_stage[:words].copy_(self._host_stage[:words], non_blocking=True)
+        kernels.stage_decode_packed(self._dev_stage, -1, 0, g)
+        self._replay(padded)
+        logits = self.model.compute_logits(g["outputs"][:bs])
+        token_ids = None
+        if self.rank == 0:
+            token_ids = self.sampler(logits, g["temperatures"][:bs]).tolist()
+        else:
+            torch.cuda.current_stream().synchronize()     # the staging buffer is rewritten by the next message
         self._check_comm()
         return token_ids
 

@@ -231,6 +231,14 @@ def test_engine_tensor_parallel_matches_oracle(golden, tp, collectives, monkeypa
                                 label=f"tp{tp} {collectives}")
 
 
+def test_engine_tensor_parallel_step_as_seven_arrays(golden, monkeypatch):
+    """Decode steps of a tensor-parallel job travel to the ranks as the packed staging buffer (ModelRunner.run_packed);
+    NV_TP_PACKED_STEPS=0 restores the message of seven arrays (run_step, the reference's own shape of it,
+    model_runner.py:206-235): same tokens, checked against the oracle like the packed form above."""
+    monkeypatch.setenv("NV_TP_PACKED_STEPS", "0")
+    test_engine_tensor_parallel_matches_oracle(golden, 2, "xgmi-graph", monkeypatch)
+
+
 @pytest.mark.parametrize("tp", [4, 8])
 def test_engine_tensor_parallel_metric_geometry(tp, monkeypatch):
     """The layer geometry of the metric configuration (Qwen2-0.5B: 14 query / 2 KV heads of 64, hidden 896,
