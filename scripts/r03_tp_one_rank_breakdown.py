@@ -41,11 +41,13 @@ def timed(obj, name, label=None):
 
 for _ in range(8):
     driver.step()
-timed(runner, "_prepare_step"); timed(runner, "_write_shm"); timed(runner, "_replay", "graph replay")
+timed(runner, "_prepare_step"); timed(runner, "_pack_decode"); timed(runner, "_write_shm"); timed(runner, "_replay", "graph replay")
 timed(runner.model, "compute_logits", "LM-head shard + gather"); timed(runner, "sampler", "sampler launch")
 import byox_vllm_amd.kernels as K
-timed(K, "stage_decode_inputs", "stage kernel")
-timed(runner, "run_step", "run_step (all of the below but the first two)")
+timed(K, "stage_decode_inputs", "stage kernel (seven arrays)")
+timed(K, "stage_decode_packed", "stage kernel (packed)")
+timed(runner, "run_step", "run_step (whole)")
+timed(runner, "run_packed", "run_packed (whole)")
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     driver.step()
