@@ -694,3 +694,37 @@ def test_prefill_of_many_rows_through_the_vendor_library_vs_oracle(golden, quant
         outs.append(got)
     assert (outs[0] - outs[1]).abs().max().item() < LOGIT_TOL
     assert torch.equal(outs[0].argmax(-1), outs[1].argmax(-1)) or (want.topk(2, -1).values.diff(dim=-1).abs().min() < LOGIT_TOL)
+
+
+def test_engine_long_prompts_through_the_vendor_library_match_oracle(golden):
+    """LLM.generate with seven prompts of about a thousand tokens, four of them sharing a 512-token prefix: the first
+    prefill step has more than 4096 rows, so its linears run through the vendor-library route, and the prompts that
+    arrive later hit the prefix cache.  Greedy tokens against the teacher-forced oracle under the same scheduler."""
+    from byox_vllm_amd import LLM, SamplingParams, kernels
+    from byox_vllm_amd.layers.rotary_embedding import get_rope
+    get_rope.cache_clear()
+    _, _, weights = _golden_weights(golden, "qwen2")
+    cfg = OM.tiny_config("qwen2", torch.bfloat16)
+    cfg.max_position_embeddings = 1100
+    rng = np.random.RandomState(12)
+    shared = rng.randint(0, 256, size=512).tolist()
+    prompts = [rng.randint(0, 256, size=1000).tolist() for _ in range(3)] + \
+              [shared + rng.randint(0, 256, size=n).tolist() for n in (470, 500, 430, 488)]
+    blocks = 7 * 64 + 8       # the shared prefix is computed once: 3000 + 982 + 500 + 430 + 488 rows in the first step
+    calls = []
+    real = kernels.gemm_many_rows
+    kernels.gemm_many_rows = lambda *a, **k: (calls.append(a[0].size(0)), real(*a, **k))[1]
+    try:
+        llm = LLM("synthetic", hf_config=cfg, state_dict=weights, kvcache_block_size=BS, num_kvcache_blocks=blocks,
+                  enforce_eager=False, max_model_len=1100, max_num_batched_tokens=8192, max_num_seqs=8)
+        calls.clear()          # the warm-up step of the constructor took the route too
+        try:
+            outs = llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), use_tqdm=False)
+        finally:
+            llm._exit()
+    finally:
+        kernels.gemm_many_rows = real
+    assert calls and min(calls) >= kernels.MANY_ROWS, calls
+    got = [o["token_ids"] for o in outs]
+    check_tokens_against_oracle(cfg, weights, prompts, got, block_size=BS, num_blocks=blocks, max_num_batched_tokens=8192,
+                                label="long prompts, vendor-library prefill")
