@@ -391,7 +391,9 @@ def test_kv_cache_sized_from_free_memory(golden):
     from byox_vllm_amd.sampling_params import SamplingParams
     _, _, weights = _golden_weights(golden, "qwen2")
     cfg = OM.tiny_config("qwen2", torch.bfloat16)
-    torch.cuda.empty_cache()
+    import gc
+    gc.collect()                                       # runners of earlier tests that are garbage but not yet collected
+    torch.cuda.empty_cache()                           # would otherwise give their memory back inside the constructor
     free, total = torch.cuda.mem_get_info()
     budget = 1 << 30                                   # ask for what is in use now plus 1 GiB
     runner = make_runner(cfg, weights, num_blocks=-1, gpu_memory_utilization=(total - free + budget) / total)
