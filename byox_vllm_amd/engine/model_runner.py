@@ -85,6 +85,11 @@ class ModelRunner:
         self.comm = None
         local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
+        # ranks that share a GPU (a rehearsal): no vendor-library products beside the all-reduce's waiting workgroups
+        self._shares_gpu = (self.world_size > max(torch.cuda.device_count(), 1)
+                            and os.environ.get("NV_GEMM_LT_SHARED_GPU", "0") != "1")     # 1: measurement aid
+        if self._shares_gpu:
+            kernels.block_many_rows(True)
         self.device = torch.device("cuda", local)
         default_dtype = torch.get_default_dtype()
         default_device = torch.get_default_device()
@@ -155,6 +160,9 @@ class ModelRunner:
         that the caller can build another runner in this process (bench.py retries eagerly, then falls back to
         replicas).  No collective is issued here: the peers may be anywhere."""
         from byox_vllm_amd.layers.linear import set_comm
+        if getattr(self, "_shares_gpu", False):
+            self._shares_gpu = False
+            kernels.block_many_rows(False)
         self.graphs, self.graph_pool, self.graph_vars = {}, None, None
         self.kv_cache = None
         for module in (self.model.modules() if getattr(self, "model", None) is not None else ()):
@@ -238,6 +246,9 @@ class ModelRunner:
             event.set()
 
     def exit(self):
+        if getattr(self, "_shares_gpu", False):
+            self._shares_gpu = False
+            kernels.block_many_rows(False)
         if self.world_size > 1 and getattr(self, "shm", None) is not None:
             self.shm.close()
             dist.barrier()

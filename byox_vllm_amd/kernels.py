@@ -299,9 +299,21 @@ def gemm_many_rows(x, w, bias=None, out=None, silu_mul=False):
     return out
 
 
+_many_rows_blocked = 0
+
+
+def block_many_rows(on: bool) -> None:
+    """Keep products off the vendor-library route while ``on`` (counted: callers pair True with False).  For jobs whose
+    ranks SHARE a GPU (rehearsals of the tensor-parallel runtime): the library's persistent stream-K workgroups and the
+    peer-memory all-reduce's workgroups both wait for partners that must be resident at the same time, and with eight
+    processes on one device the all-reduce's bounded wait has been seen to run out."""
+    global _many_rows_blocked
+    _many_rows_blocked = max(0, _many_rows_blocked + (1 if on else -1))
+
+
 def use_many_rows_path(M, K, N) -> bool:
-    return bool(MANY_ROWS) and M >= MANY_ROWS and K % 128 == 0 and N % 16 == 0 and lib().nv_gemm_lt_available() == 1 \
-        and not torch.cuda.is_current_stream_capturing()
+    return bool(MANY_ROWS) and M >= MANY_ROWS and not _many_rows_blocked and K % 128 == 0 and N % 16 == 0 \
+        and lib().nv_gemm_lt_available() == 1 and not torch.cuda.is_current_stream_capturing()
 
 
 def gemm(x, w, bias=None, out=None, split_k=None, silu_mul=False, partial_out=False):
