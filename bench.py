@@ -284,6 +284,9 @@ def run_generate_workload(args):
 
 KEEPER = r"""
 import os, select, signal, sys
+# a launcher that ends a failed job signals the ranks' whole process groups, this process included, possibly while
+# the rank that died is still writing its core file and has not closed the pipe yet: stay until the pipe says so
+signal.signal(signal.SIGTERM, signal.SIG_IGN); signal.signal(signal.SIGINT, signal.SIG_IGN)
 deadline = float(sys.argv[1]); parent = int(sys.argv[2])
 line, buf = None, b""
 while True:

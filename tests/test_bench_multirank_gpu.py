@@ -29,7 +29,7 @@ def _bench(extra, env_extra=None, launcher=False, expect_failure=False):
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert (out.returncode != 0) == expect_failure, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, out.stdout[-2000:]          # exactly one line, from rank 0
+    assert len(lines) == 1, out.stdout[-2000:] + "\n--- stderr ---\n" + out.stderr[-6000:]   # exactly one line, from rank 0
     return json.loads(lines[0])
 
 
