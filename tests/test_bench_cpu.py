@@ -59,6 +59,6 @@ def test_keeper_ends_a_stalled_job_and_prints_the_line():
 def test_keeper_outlives_the_launchers_termination_signal():
     """A launcher that ends a failed job signals whole process groups: the keeper may get SIGTERM while the rank that
     died has not closed the pipe yet (it is still writing its core file).  It stays, and prints once the pipe closes."""
-    out = _keeper_parent("import signal; os.kill(k.proc.pid, signal.SIGTERM); time.sleep(1.0); "
+    out = _keeper_parent("import signal; time.sleep(1.0); os.kill(k.proc.pid, signal.SIGTERM); time.sleep(1.0); "
                          "assert k.proc.poll() is None, 'the keeper left on SIGTERM'; os.abort()")
     assert out.returncode != 0 and out.stdout.strip() == '{"value": 2}', (out.stdout, out.stderr[-500:])
