@@ -597,7 +597,23 @@ class ModelRunner:
         for layer in self.model.model.layers:
             layer.self_attn.attn.decode_splits = splits
 
+    def _warm_vendor_library(self) -> None:
+        """The first hipBLASLt call of a process loads the library and its kernels (0.2 s with a warm page cache,
+        longer from a cold disk).  Pay that here, outside any step, and let the ranks of a tensor-parallel job meet
+        again afterwards: inside the warm-up prefill it would make ranks arrive at their first all-reduce seconds
+        apart, and the peer-memory all-reduce waits for a peer for two seconds only."""
+        rows = kernels.MANY_ROWS
+        if rows and kernels.use_many_rows_path(rows, 128, 128):
+            from byox_vllm_amd.layers.quant import LinearWeight
+            dtype = self.config.hf_config.dtype
+            x = torch.zeros(rows, 128, dtype=dtype, device=self.device)
+            kernels.gemm_many_rows(x, LinearWeight.dense(torch.zeros(128, 128, dtype=dtype, device=self.device)))
+            torch.cuda.synchronize()
+        if self.world_size > 1 and dist.is_initialized():
+            dist.barrier()
+
     def _warmup_model(self):
+        self._warm_vendor_library()
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         max_tokens, max_len = self.config.max_num_batched_tokens, self.config.max_model_len
