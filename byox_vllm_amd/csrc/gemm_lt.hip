@@ -28,7 +28,9 @@ struct LtApi {
   decltype(&hipblasLtCreate) Create = nullptr;
   decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
   decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
+  decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
   decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
+  decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
   decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
   decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
   decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
@@ -55,7 +57,9 @@ LtApi& lt_api() {
     }
     api.ok = bind(so, "hipblasLtCreate", api.Create, api) && bind(so, "hipblasLtMatmulDescCreate", api.DescCreate, api) &&
              bind(so, "hipblasLtMatmulDescSetAttribute", api.DescSet, api) &&
+             bind(so, "hipblasLtMatmulDescDestroy", api.DescDestroy, api) &&
              bind(so, "hipblasLtMatrixLayoutCreate", api.LayoutCreate, api) &&
+             bind(so, "hipblasLtMatrixLayoutDestroy", api.LayoutDestroy, api) &&
              bind(so, "hipblasLtMatmulPreferenceCreate", api.PrefCreate, api) &&
              bind(so, "hipblasLtMatmulPreferenceSetAttribute", api.PrefSet, api) &&
              bind(so, "hipblasLtMatmulPreferenceDestroy", api.PrefDestroy, api) &&
@@ -64,8 +68,10 @@ LtApi& lt_api() {
   return api;
 }
 
-// One product shape on one device: descriptors and the algorithm the library's heuristic chose for it.  Kept for the
-// life of the process (a model has four shapes per row count).
+// One product shape on one device: descriptors and the algorithm the library's heuristic chose for it.  A model has four
+// shapes per row count and a serving process sees many row counts: the table is emptied when it reaches NV_LT_MAX_PLANS
+// (descriptors are host objects, read when a product is launched, so none is in use between calls).
+#define NV_LT_MAX_PLANS 512
 struct LtPlan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
@@ -77,6 +83,14 @@ typedef std::tuple<int, int, int, int, int, int, int64_t, int64_t, size_t> LtKey
 std::mutex g_lt_mutex;
 std::map<int, hipblasLtHandle_t> g_lt_handles;
 std::map<LtKey, LtPlan> g_lt_plans;
+
+void destroy_plan(LtApi& api, LtPlan& p) {
+  if (p.desc) api.DescDestroy(p.desc);
+  if (p.a) api.LayoutDestroy(p.a);
+  if (p.b) api.LayoutDestroy(p.b);
+  if (p.c) api.LayoutDestroy(p.c);
+  p = LtPlan();
+}
 
 }  // namespace
 
@@ -127,6 +141,7 @@ extern "C" int nv_gemm_lt(const void* x, int64_t x_row_stride, const void* w_row
     ok = ok && api.LayoutCreate(&p.b, t, (uint64_t)K, (uint64_t)M, x_row_stride) == HIPBLAS_STATUS_SUCCESS;
     ok = ok && api.LayoutCreate(&p.c, t, (uint64_t)N, (uint64_t)M, out_row_stride) == HIPBLAS_STATUS_SUCCESS;
     if (!ok) {
+      destroy_plan(api, p);
       nv_set_error("nv_gemm_lt: descriptor set-up failed (M=%d N=%d K=%d)", M, N, K);
       return NV_ERR_LAUNCH;
     }
@@ -147,12 +162,17 @@ extern "C" int nv_gemm_lt(const void* x, int64_t x_row_stride, const void* w_row
     for (int i = 0; ok && i < n_found && pick < 0; ++i)
       if (found[i].state == HIPBLAS_STATUS_SUCCESS && found[i].workspaceSize <= limit) pick = i;
     if (!ok || pick < 0) {
+      destroy_plan(api, p);
       nv_set_error("nv_gemm_lt: the library offers no algorithm for M=%d N=%d K=%d within %llu bytes of workspace", M, N, K,
                    (unsigned long long)limit);
       return NV_ERR_INVALID;
     }
     p.algo = found[pick].algo;
     p.workspace = found[pick].workspaceSize;
+    if (g_lt_plans.size() >= NV_LT_MAX_PLANS) {
+      for (auto& kv : g_lt_plans) destroy_plan(api, kv.second);
+      g_lt_plans.clear();
+    }
     it = g_lt_plans.emplace(key, p).first;
   }
   LtPlan& p = it->second;

@@ -1216,3 +1216,19 @@ def test_result_store_policy_changes_no_bit(fmt):
     for k in plain:
         assert torch.equal(plain[k], hinted[k]), k
     assert lib().nv_set_result_policy(2) != 0 and lib().nv_get_result_policy() == 0
+
+
+def test_vendor_library_plan_table_is_bounded():
+    """A serving process sees many prefill row counts: nv_gemm_lt keeps one plan per (rows, shape) and empties the table
+    when it holds 512.  Six hundred row counts in a row, every product still the right one."""
+    from byox_vllm_amd import kernels
+    from byox_vllm_amd.layers.quant import LinearWeight
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(128, 128, generator=g) * 0.05).to(torch.bfloat16)
+    x = torch.randn(1000, 128, generator=g).to(torch.bfloat16)
+    lw, xd = LinearWeight.dense(dev(w)), dev(x)
+    want = torch.nn.functional.linear(x.double(), w.double())
+    for rows in range(400, 1000):
+        got = kernels.gemm_many_rows(xd[:rows], lw)
+        if rows % 97 == 0 or rows == 999:
+            ulp_close(got, want[:rows].to(torch.bfloat16), "bf16", ulps=1.0)
